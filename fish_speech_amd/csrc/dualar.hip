@@ -1,0 +1,889 @@
+// dualar.hip -- host side of the Dual-AR decoder behind the C ABI (include/fishmi.h):
+// weight arena layout, paged KV allocator, per-slot state, the frame step and its hipGraph.
+//
+// Reference call path replaced here (fish_speech/models/text2semantic/):
+//   generate / decode_n_tokens / decode_one_token_ar   inference.py:96-359
+//   DualARTransformer.forward_generate(_fast)          llama.py:390-466,799-828
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "dualar_kernels.h"
+
+using namespace fmi;
+
+namespace {
+
+struct LayerW {
+  bf16_t *wqkv, *wo, *w13, *w2, *attn_norm, *ffn_norm, *q_norm, *k_norm;
+};
+
+struct Dims {
+  int dim, H, KVH, D, ffn, qkv;
+};
+
+struct Workspace {
+  int rows = 0;
+  bf16_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *ao = nullptr, *act = nullptr;
+  int32_t *row_slot = nullptr, *row_pos = nullptr, *last_rows = nullptr;
+};
+
+}  // namespace
+
+struct fmi_dualar {
+  fmi_dualar_config cfg;
+  Dims slow, fast;
+  char* arena = nullptr;
+  int64_t arena_bytes = 0;
+  // arena regions
+  std::vector<LayerW> L, FL;
+  bf16_t *emb = nullptr, *cb_emb = nullptr, *norm = nullptr, *head_live = nullptr, *fast_emb = nullptr,
+         *fast_norm = nullptr, *fast_out = nullptr, *rope = nullptr, *fast_rope = nullptr;
+  int32_t* live_ids = nullptr;
+  int n_live = 0, n_live_pad = 0;
+  std::set<std::string> loaded;
+  bool ready = false, rope_loaded = false, fast_rope_loaded = false;
+
+  // runtime
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  int max_batch = 0, max_seq = 0, n_pages = 0, max_pages = 0, max_frames = 0;
+  std::vector<bf16_t*> kpool, vpool, fkc, fvc;
+  SlotState st{};
+  std::vector<int> free_pages;
+  std::vector<std::vector<int>> slot_pages;
+  Workspace ws;
+  bf16_t *hn = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
+  bool trace = false, use_graph = true, ignore_eos = false;
+  std::map<int, hipGraphExec_t> graphs;
+  void* staging = nullptr;
+  size_t staging_bytes = 0;
+  float last_ms = 0.f;
+  int launches = 0;  // counted while building one frame
+};
+
+namespace {
+
+Dims slow_dims(const fmi_dualar_config& c) {
+  return {c.dim, c.n_head, c.n_local_heads, c.head_dim, c.intermediate_size,
+          (c.n_head + 2 * c.n_local_heads) * c.head_dim};
+}
+Dims fast_dims(const fmi_dualar_config& c) {
+  return {c.fast_dim, c.fast_n_head, c.fast_n_local_heads, c.fast_head_dim, c.fast_intermediate_size,
+          (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim};
+}
+
+int count_live(const fmi_dualar_config& c) {
+  int n = c.semantic_end_id - c.semantic_begin_id + 1;
+  if (c.im_end_id < c.semantic_begin_id || c.im_end_id > c.semantic_end_id) n += 1;
+  return n;
+}
+
+int validate(const fmi_dualar_config& c) {
+  FMI_REQUIRE(c.dim > 0 && c.dim % 32 == 0, "dim=%d must be a positive multiple of 32", c.dim);
+  FMI_REQUIRE(c.fast_dim == c.dim, "fast_dim != dim (fast_project_in Linear) is not supported");
+  FMI_REQUIRE(c.intermediate_size % 32 == 0 && c.fast_intermediate_size % 32 == 0, "intermediate_size %% 32");
+  FMI_REQUIRE(c.head_dim == 32 || c.head_dim == 64 || c.head_dim == 128, "head_dim must be 32/64/128");
+  FMI_REQUIRE(c.fast_head_dim == 32 || c.fast_head_dim == 64 || c.fast_head_dim == 128, "fast_head_dim 32/64/128");
+  FMI_REQUIRE(c.n_head % c.n_local_heads == 0 && c.fast_n_head % c.fast_n_local_heads == 0, "GQA ratio");
+  int g = c.n_head / c.n_local_heads;
+  FMI_REQUIRE(g == 1 || g == 2 || g == 4, "n_head/n_local_heads must be 1, 2 or 4");
+  FMI_REQUIRE((c.n_head * c.head_dim) % 32 == 0 && (c.fast_n_head * c.fast_head_dim) % 32 == 0, "H*D %% 32");
+  FMI_REQUIRE(c.codebook_size % 16 == 0, "codebook_size %% 16");
+  FMI_REQUIRE(c.num_codebooks >= 2 && c.num_codebooks <= 16, "num_codebooks in [2,16]");
+  FMI_REQUIRE(c.semantic_begin_id >= 0 && c.semantic_end_id >= c.semantic_begin_id &&
+                  c.semantic_end_id < c.vocab_size && c.im_end_id >= 0 && c.im_end_id < c.vocab_size,
+              "semantic/im_end ids out of range");
+  FMI_REQUIRE(c.max_seq_len > 0, "max_seq_len");
+  return FMI_OK;
+}
+
+// Walk the arena layout.  With h == nullptr only the size is computed.
+int64_t layout(const fmi_dualar_config& c, fmi_dualar* h) {
+  int64_t off = 0;
+  char* base = h ? h->arena : nullptr;
+  auto take = [&](int64_t elems, int64_t esize) -> void* {
+    void* p = base ? base + off : nullptr;
+    off = align_up(off + elems * esize, 256);
+    return p;
+  };
+  const Dims s = slow_dims(c), f = fast_dims(c);
+  const int n_live = count_live(c), n_live_pad = (int)align_up(n_live, 16);
+  auto layer = [&](const Dims& d) {
+    LayerW w;
+    w.wqkv = (bf16_t*)take((int64_t)d.qkv * d.dim, 2);
+    w.wo = (bf16_t*)take((int64_t)d.dim * d.H * d.D, 2);
+    w.w13 = (bf16_t*)take((int64_t)2 * d.ffn * d.dim, 2);
+    w.w2 = (bf16_t*)take((int64_t)d.dim * d.ffn, 2);
+    w.attn_norm = (bf16_t*)take(d.dim, 2);
+    w.ffn_norm = (bf16_t*)take(d.dim, 2);
+    w.q_norm = (bf16_t*)take(d.D, 2);
+    w.k_norm = (bf16_t*)take(d.D, 2);
+    return w;
+  };
+  bf16_t* emb = (bf16_t*)take((int64_t)c.vocab_size * c.dim, 2);
+  bf16_t* cb = (bf16_t*)take((int64_t)c.codebook_size * c.num_codebooks * c.dim, 2);
+  bf16_t* norm = (bf16_t*)take(c.dim, 2);
+  bf16_t* head = (bf16_t*)take((int64_t)n_live_pad * c.dim, 2);
+  int32_t* ids = (int32_t*)take(n_live_pad, 4);
+  bf16_t* femb = (bf16_t*)take((int64_t)c.codebook_size * c.fast_dim, 2);
+  bf16_t* fnorm = (bf16_t*)take(c.fast_dim, 2);
+  bf16_t* fout = (bf16_t*)take((int64_t)c.codebook_size * c.fast_dim, 2);
+  bf16_t* rope = (bf16_t*)take((int64_t)c.max_seq_len * c.head_dim, 2);
+  bf16_t* frope = (bf16_t*)take((int64_t)c.num_codebooks * c.fast_head_dim, 2);
+  std::vector<LayerW> L, FL;
+  for (int i = 0; i < c.n_layer; ++i) L.push_back(layer(s));
+  for (int i = 0; i < c.n_fast_layer; ++i) FL.push_back(layer(f));
+  if (h) {
+    h->emb = emb; h->cb_emb = cb; h->norm = norm; h->head_live = head; h->live_ids = ids;
+    h->fast_emb = femb; h->fast_norm = fnorm; h->fast_out = fout; h->rope = rope; h->fast_rope = frope;
+    h->L = L; h->FL = FL; h->n_live = n_live; h->n_live_pad = n_live_pad;
+  }
+  return off;
+}
+
+int ensure_staging(fmi_dualar* h, size_t bytes) {
+  if (h->staging_bytes >= bytes) return FMI_OK;
+  if (h->staging) FMI_CHECK_HIP(hipFree(h->staging));
+  h->staging = nullptr;
+  h->staging_bytes = 0;
+  FMI_CHECK_HIP(hipMalloc(&h->staging, bytes));
+  h->staging_bytes = bytes;
+  return FMI_OK;
+}
+
+int sync_in(fmi_dualar* h, void* user_stream) {
+  FMI_CHECK_HIP(hipEventRecord(h->ev_in, (hipStream_t)user_stream));
+  FMI_CHECK_HIP(hipStreamWaitEvent(h->stream, h->ev_in, 0));
+  return FMI_OK;
+}
+int sync_out(fmi_dualar* h, void* user_stream) {
+  FMI_CHECK_HIP(hipEventRecord(h->ev_out, h->stream));
+  FMI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)user_stream, h->ev_out, 0));
+  return FMI_OK;
+}
+
+template <typename T>
+int dev_alloc(T** p, int64_t n) {
+  FMI_CHECK_HIP(hipMalloc((void**)p, (size_t)(n * (int64_t)sizeof(T))));
+  FMI_CHECK_HIP(hipMemset(*p, 0, (size_t)(n * (int64_t)sizeof(T))));
+  return FMI_OK;
+}
+
+int free_ws(Workspace& w) {
+  void* ptrs[] = {w.x, w.xn, w.qkv, w.q, w.ao, w.act, w.row_slot, w.row_pos, w.last_rows};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  w = Workspace();
+  return FMI_OK;
+}
+
+void drop_graphs(fmi_dualar* h) {
+  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+  h->graphs.clear();
+}
+
+int ensure_rows(fmi_dualar* h, int rows) {
+  if (h->ws.rows >= rows) return FMI_OK;
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  drop_graphs(h);
+  free_ws(h->ws);
+  const Dims& s = h->slow;
+  const Dims& f = h->fast;
+  const int64_t dim = std::max(s.dim, f.dim), qkv = std::max(s.qkv, f.qkv), hd = std::max(s.H * s.D, f.H * f.D),
+                ffn = std::max(s.ffn, f.ffn);
+  Workspace& w = h->ws;
+  FMI_CHECK(dev_alloc(&w.x, rows * dim));
+  FMI_CHECK(dev_alloc(&w.xn, rows * dim));
+  FMI_CHECK(dev_alloc(&w.qkv, rows * qkv));
+  FMI_CHECK(dev_alloc(&w.q, rows * hd));
+  FMI_CHECK(dev_alloc(&w.ao, rows * hd));
+  FMI_CHECK(dev_alloc(&w.act, rows * ffn));
+  FMI_CHECK(dev_alloc(&w.row_slot, rows));
+  FMI_CHECK(dev_alloc(&w.row_pos, rows));
+  FMI_CHECK(dev_alloc(&w.last_rows, std::max(rows, 1)));
+  w.rows = rows;
+  return FMI_OK;
+}
+
+// out = linear(norm?(x)) for M rows; picks the skinny (fused norm) or tiled path.
+int linear(fmi_dualar* h, const bf16_t* x, int ldx, const bf16_t* wp, const bf16_t* norm_w, const bf16_t* res,
+           int ldr, bf16_t* out, int ldo, int M, int N, int K, int epi, hipStream_t s) {
+  LinearArgs a{};
+  a.wp = wp; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = h->cfg.norm_eps; a.res = res; a.ldr = ldr;
+  a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epi = epi;
+  if (M <= 16) {
+    h->launches += 1;
+    return launch_linear_skinny(a, s);
+  }
+  if (norm_w) {
+    FMI_CHECK(launch_rmsnorm_rows(x, ldx, norm_w, h->cfg.norm_eps, h->ws.xn, K, M, K, s));
+    a.x = h->ws.xn;
+    a.ldx = K;
+    a.norm_w = nullptr;
+    h->launches += 1;
+  }
+  h->launches += 1;
+  return launch_linear_tiled(a, s);
+}
+
+// one transformer block (llama.py:839-844) over `rows` rows of the residual stream x (in place)
+int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, const int32_t* row_slot,
+               const int32_t* row_pos, hipStream_t s) {
+  const Dims& d = h->slow;
+  Workspace& ws = h->ws;
+  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, rows, d.qkv, d.dim, EPI_STORE, s));
+  AttnArgs a{};
+  a.qkv = ws.qkv; a.q = ws.q; a.out = ws.ao; a.kpool = h->kpool[layer]; a.vpool = h->vpool[layer];
+  a.qnw = h->cfg.attention_qk_norm ? w.q_norm : nullptr;
+  a.knw = h->cfg.attention_qk_norm ? w.k_norm : nullptr;
+  a.rope = h->rope; a.row_slot = row_slot; a.row_pos = row_pos; a.block_table = h->st.block_table;
+  a.slot_pos = h->st.pos; a.max_pages = h->max_pages; a.rows = rows; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
+  a.eps = h->cfg.norm_eps;
+  FMI_CHECK(launch_attn_prep(a, s));
+  FMI_CHECK(launch_attn(a, s));
+  h->launches += 2;
+  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s));
+  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.ffn, EPI_RESIDUAL, s));
+  return FMI_OK;
+}
+
+int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int pos, const int32_t* row_slot,
+               hipStream_t s) {
+  const Dims& d = h->fast;
+  Workspace& ws = h->ws;
+  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s));
+  FastAttnArgs a{};
+  a.qkv = ws.qkv; a.out = ws.ao; a.kc = h->fkc[layer]; a.vc = h->fvc[layer];
+  a.qnw = h->cfg.fast_attention_qk_norm ? w.q_norm : nullptr;
+  a.knw = h->cfg.fast_attention_qk_norm ? w.k_norm : nullptr;
+  a.rope = h->fast_rope; a.row_slot = row_slot; a.B = B; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
+  a.ncb = h->cfg.num_codebooks; a.pos = pos; a.eps = h->cfg.norm_eps;
+  FMI_CHECK(launch_fast_attn(a, s));
+  h->launches += 1;
+  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s));
+  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s));
+  return FMI_OK;
+}
+
+// everything after the slow transformer for B utterances whose last hidden rows are xl[B][dim]:
+// final norm, restricted tied head, constrained sampling + RAS, the fast-AR chain
+// (decode_one_token_ar, inference.py:108-181).
+int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStream_t s) {
+  const fmi_dualar_config& c = h->cfg;
+  const int dim = c.dim;
+  FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s));
+  h->launches += 1;
+  FMI_CHECK(linear(h, h->hn, dim, h->head_live, nullptr, nullptr, 0, h->logits, h->n_live_pad, B, h->n_live_pad, dim,
+                   EPI_STORE, s));
+  SampleArgs sa{};
+  sa.logits = h->logits; sa.B = B; sa.n = h->n_live; sa.ld = h->n_live_pad; sa.ids = h->live_ids;
+  sa.row_slot = row_slot; sa.st = h->st; sa.mode = 0; sa.cb = 0; sa.sem_begin = c.semantic_begin_id;
+  sa.sem_end = c.semantic_end_id; sa.im_end = h->ignore_eos ? -1 : c.im_end_id; sa.cbs = c.codebook_size; sa.fast_emb = h->fast_emb;
+  sa.xf = h->xf; sa.fdim = c.fast_dim;
+  FMI_CHECK(launch_sample(sa, s));
+  h->launches += 1;
+  // fast step 0 on the hidden state; its logits are discarded (inference.py:148-149)
+  bf16_t* f0 = h->hn;
+  if (!c.norm_fastlayer_input) {
+    FMI_CHECK_HIP(hipMemcpyAsync(h->ws.xn, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
+    f0 = h->ws.xn;
+  }
+  for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, f0, B, 0, row_slot, s));
+  for (int cb = 1; cb < c.num_codebooks; ++cb) {
+    for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, B, cb, row_slot, s));
+    FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, B,
+                     c.codebook_size, c.fast_dim, EPI_STORE, s));
+    if (h->trace) {
+      FMI_CHECK_HIP(hipMemcpy2DAsync(h->ftrace + (int64_t)cb * c.codebook_size,
+                                     (size_t)c.num_codebooks * c.codebook_size * 2, h->flogits,
+                                     (size_t)c.codebook_size * 2, (size_t)c.codebook_size * 2, B,
+                                     hipMemcpyDeviceToDevice, s));
+    }
+    SampleArgs fa = sa;
+    fa.logits = h->flogits; fa.n = c.codebook_size; fa.ld = c.codebook_size; fa.ids = nullptr; fa.mode = 1;
+    fa.cb = cb;
+    FMI_CHECK(launch_sample(fa, s));
+    h->launches += 1;
+  }
+  return FMI_OK;
+}
+
+// one decode frame for the B slots listed in ws.row_slot
+int decode_frame(fmi_dualar* h, int B, hipStream_t s) {
+  const fmi_dualar_config& c = h->cfg;
+  h->launches = 0;
+  EmbedArgs e{};
+  e.emb = h->emb; e.cb_emb = h->cb_emb; e.tokens = h->st.cur; e.row_slot = h->ws.row_slot; e.out = h->ws.x;
+  e.rows = B; e.dim = c.dim; e.ncb = c.num_codebooks; e.cbs = c.codebook_size; e.sem_begin = c.semantic_begin_id;
+  e.sem_end = c.semantic_end_id; e.scale = c.scale_codebook_embeddings;
+  FMI_CHECK(launch_embed(e, s));
+  h->launches += 1;
+  for (int i = 0; i < c.n_layer; ++i)
+    FMI_CHECK(block_slow(h, h->L[i], i, h->ws.x, B, h->ws.row_slot, nullptr, s));
+  return tail(h, h->ws.x, B, h->ws.row_slot, s);
+}
+
+int reserve_pages(fmi_dualar* h, int slot, int upto_pos_exclusive) {
+  const int need = cdiv(std::max(upto_pos_exclusive, 1), KV_PAGE);
+  FMI_REQUIRE(need <= h->max_pages, "slot %d needs %d pages > max %d (raise max_seq_len)", slot, need, h->max_pages);
+  std::vector<int>& pg = h->slot_pages[slot];
+  bool changed = false;
+  while ((int)pg.size() < need) {
+    if (h->free_pages.empty()) return set_error(FMI_ENOMEM, "KV page pool exhausted");
+    pg.push_back(h->free_pages.back());
+    h->free_pages.pop_back();
+    changed = true;
+  }
+  if (changed)
+    FMI_CHECK_HIP(hipMemcpyAsync(h->st.block_table + (int64_t)slot * h->max_pages, pg.data(), pg.size() * 4,
+                                 hipMemcpyHostToDevice, h->stream));
+  return FMI_OK;
+}
+
+int set_slot(fmi_dualar* h, int slot, int pos, int frame, int limit, const fmi_sampling& sp, bool zero_window) {
+  hipStream_t s = h->stream;
+  const int32_t zero = 0;
+  const float t = rbf(sp.temperature), p = rbf(sp.top_p);
+#define PUT(arr, val) FMI_CHECK_HIP(hipMemcpyAsync((arr) + slot, &(val), 4, hipMemcpyHostToDevice, s))
+  PUT(h->st.pos, pos);
+  PUT(h->st.frame, frame);
+  PUT(h->st.done, zero);
+  PUT(h->st.limit, limit);
+  PUT(h->st.temperature, t);
+  PUT(h->st.top_p, p);
+  PUT(h->st.top_k, sp.top_k);
+  PUT(h->st.seed, sp.seed);
+  PUT(h->st.use_ras, sp.use_ras);
+#undef PUT
+  if (zero_window)
+    FMI_CHECK_HIP(hipMemsetAsync(h->st.window + (int64_t)slot * h->st.ncb1 * RAS_WIN, 0,
+                                 (size_t)h->st.ncb1 * RAS_WIN * 4, s));
+  return FMI_OK;
+}
+
+int check_slot(fmi_dualar* h, int slot) {
+  FMI_REQUIRE(h->max_batch > 0, "setup_caches has not been called");
+  FMI_REQUIRE(slot >= 0 && slot < h->max_batch, "slot %d out of range [0,%d)", slot, h->max_batch);
+  return FMI_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+int fmi_version(void) { return 1; }
+const char* fmi_last_error(void) { return g_last_error.c_str(); }
+
+int fmi_device_arch(char* buf, size_t n) {
+  int dev = 0;
+  FMI_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  FMI_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, n, "%s", p.gcnArchName);
+  return FMI_OK;
+}
+
+int64_t fmi_dualar_arena_bytes(const fmi_dualar_config* cfg) {
+  if (!cfg || validate(*cfg) != FMI_OK) return -1;
+  return layout(*cfg, nullptr);
+}
+
+int fmi_dualar_create(const fmi_dualar_config* cfg, void* arena_dev, int64_t arena_bytes, fmi_dualar** out) {
+  FMI_REQUIRE(cfg && arena_dev && out, "null argument");
+  FMI_CHECK(validate(*cfg));
+  const int64_t need = layout(*cfg, nullptr);
+  FMI_REQUIRE(arena_bytes >= need, "arena too small: %lld < %lld", (long long)arena_bytes, (long long)need);
+  FMI_REQUIRE(((uintptr_t)arena_dev & 255) == 0, "arena must be 256-byte aligned");
+  fmi_dualar* h = new fmi_dualar();
+  h->cfg = *cfg;
+  h->slow = slow_dims(*cfg);
+  h->fast = fast_dims(*cfg);
+  h->arena = (char*)arena_dev;
+  h->arena_bytes = arena_bytes;
+  layout(*cfg, h);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess) {
+    delete h;
+    return set_error(FMI_EHIP, "stream/event creation failed (no GPU?)");
+  }
+  *out = h;
+  return FMI_OK;
+}
+
+void fmi_dualar_destroy(fmi_dualar* h) {
+  if (!h) return;
+  hipStreamSynchronize(h->stream);
+  drop_graphs(h);
+  free_ws(h->ws);
+  for (auto p : h->kpool) hipFree(p);
+  for (auto p : h->vpool) hipFree(p);
+  for (auto p : h->fkc) hipFree(p);
+  for (auto p : h->fvc) hipFree(p);
+  void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
+                  h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
+                  h->hn, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  hipEventDestroy(h->ev_in);
+  hipEventDestroy(h->ev_out);
+  hipEventDestroy(h->ev_t0);
+  hipEventDestroy(h->ev_t1);
+  hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int fmi_dualar_load_tensor(fmi_dualar* h, const char* name_c, const void* src, int64_t rows, int64_t cols,
+                           int src_is_device, void* stream) {
+  FMI_REQUIRE(h && name_c && src, "null argument");
+  const std::string name(name_c);
+  const fmi_dualar_config& c = h->cfg;
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  const bf16_t* dsrc = (const bf16_t*)src;
+  if (!src_is_device) {
+    FMI_CHECK(ensure_staging(h, (size_t)(rows * cols * 2)));
+    FMI_CHECK_HIP(hipMemcpyAsync(h->staging, src, (size_t)(rows * cols * 2), hipMemcpyHostToDevice, s));
+    dsrc = (const bf16_t*)h->staging;
+  }
+  auto expect = [&](int64_t r, int64_t cc) -> int {
+    if (rows != r || cols != cc)
+      return set_error(FMI_EINVAL, "%s: shape (%lld,%lld) != expected (%lld,%lld)", name.c_str(), (long long)rows,
+                       (long long)cols, (long long)r, (long long)cc);
+    return FMI_OK;
+  };
+  auto copy = [&](bf16_t* dst) -> int {
+    FMI_CHECK_HIP(hipMemcpyAsync(dst, dsrc, (size_t)(rows * cols * 2), hipMemcpyDeviceToDevice, s));
+    return FMI_OK;
+  };
+  int rc = FMI_OK;
+  if (name == "embeddings.weight") { FMI_CHECK(expect(c.vocab_size, c.dim)); rc = copy(h->emb); }
+  else if (name == "codebook_embeddings.weight") { FMI_CHECK(expect((int64_t)c.codebook_size * c.num_codebooks, c.dim)); rc = copy(h->cb_emb); }
+  else if (name == "norm.weight") { FMI_CHECK(expect(1, c.dim)); rc = copy(h->norm); }
+  else if (name == "fast_embeddings.weight") { FMI_CHECK(expect(c.codebook_size, c.fast_dim)); rc = copy(h->fast_emb); }
+  else if (name == "fast_norm.weight") { FMI_CHECK(expect(1, c.fast_dim)); rc = copy(h->fast_norm); }
+  else if (name == "fast_output.weight") { FMI_CHECK(expect(c.codebook_size, c.fast_dim)); rc = launch_pack_weight(dsrc, h->fast_out, (int)rows, (int)cols, 0, s); }
+  else if (name == "freqs_cis") { FMI_CHECK(expect(c.max_seq_len, c.head_dim)); rc = copy(h->rope); h->rope_loaded = true; }
+  else if (name == "fast_freqs_cis") { FMI_CHECK(expect(c.num_codebooks, c.fast_head_dim)); rc = copy(h->fast_rope); h->fast_rope_loaded = true; }
+  else {
+    const bool fastl = name.rfind("fast_layers.", 0) == 0;
+    const bool slowl = name.rfind("layers.", 0) == 0;
+    if (!fastl && !slowl) return set_error(FMI_EINVAL, "unknown tensor name '%s'", name.c_str());
+    const size_t p0 = fastl ? 12 : 7;
+    const size_t dot = name.find('.', p0);
+    if (dot == std::string::npos) return set_error(FMI_EINVAL, "bad tensor name '%s'", name.c_str());
+    const int idx = atoi(name.substr(p0, dot - p0).c_str());
+    const std::string sub = name.substr(dot + 1);
+    const Dims& d = fastl ? h->fast : h->slow;
+    std::vector<LayerW>& LL = fastl ? h->FL : h->L;
+    if (idx < 0 || idx >= (int)LL.size()) return set_error(FMI_EINVAL, "layer index out of range in '%s'", name.c_str());
+    LayerW& w = LL[idx];
+    if (sub == "attention.wqkv.weight") { FMI_CHECK(expect(d.qkv, d.dim)); rc = launch_pack_weight(dsrc, w.wqkv, d.qkv, d.dim, 0, s); }
+    else if (sub == "attention.wo.weight") { FMI_CHECK(expect(d.dim, d.H * d.D)); rc = launch_pack_weight(dsrc, w.wo, d.dim, d.H * d.D, 0, s); }
+    else if (sub == "feed_forward.w1.weight") { FMI_CHECK(expect(d.ffn, d.dim)); rc = launch_pack_weight(dsrc, w.w13, d.ffn, d.dim, 1, s); }
+    else if (sub == "feed_forward.w3.weight") { FMI_CHECK(expect(d.ffn, d.dim)); rc = launch_pack_weight(dsrc, w.w13, d.ffn, d.dim, 2, s); }
+    else if (sub == "feed_forward.w2.weight") { FMI_CHECK(expect(d.dim, d.ffn)); rc = launch_pack_weight(dsrc, w.w2, d.dim, d.ffn, 0, s); }
+    else if (sub == "attention_norm.weight") { FMI_CHECK(expect(1, d.dim)); rc = copy(w.attn_norm); }
+    else if (sub == "ffn_norm.weight") { FMI_CHECK(expect(1, d.dim)); rc = copy(w.ffn_norm); }
+    else if (sub == "attention.q_norm.weight") { FMI_CHECK(expect(1, d.D)); rc = copy(w.q_norm); }
+    else if (sub == "attention.k_norm.weight") { FMI_CHECK(expect(1, d.D)); rc = copy(w.k_norm); }
+    else return set_error(FMI_EINVAL, "unknown tensor name '%s'", name.c_str());
+  }
+  FMI_CHECK(rc);
+  if (!src_is_device) FMI_CHECK_HIP(hipStreamSynchronize(s));  // staging buffer is reused
+  h->loaded.insert(name);
+  return sync_out(h, stream);
+}
+
+int fmi_dualar_finalize_weights(fmi_dualar* h, void* stream) {
+  FMI_REQUIRE(h, "null handle");
+  const fmi_dualar_config& c = h->cfg;
+  // completeness check
+  std::vector<std::string> need = {"embeddings.weight", "codebook_embeddings.weight", "norm.weight",
+                                   "fast_embeddings.weight", "fast_norm.weight", "fast_output.weight"};
+  auto add_layer = [&](const std::string& pre, bool qk) {
+    for (const char* sfx : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w1.weight",
+                            "feed_forward.w3.weight", "feed_forward.w2.weight", "attention_norm.weight",
+                            "ffn_norm.weight"})
+      need.push_back(pre + sfx);
+    if (qk) {
+      need.push_back(pre + "attention.q_norm.weight");
+      need.push_back(pre + "attention.k_norm.weight");
+    }
+  };
+  for (int i = 0; i < c.n_layer; ++i) add_layer("layers." + std::to_string(i) + ".", c.attention_qk_norm);
+  for (int i = 0; i < c.n_fast_layer; ++i) add_layer("fast_layers." + std::to_string(i) + ".", c.fast_attention_qk_norm);
+  for (const auto& n : need)
+    if (!h->loaded.count(n)) return set_error(FMI_ESTATE, "tensor '%s' was never loaded", n.c_str());
+
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  // live LM-head rows in ascending vocab order (ties resolve to the lowest vocab id)
+  std::vector<int32_t> ids;
+  const bool im_inside = c.im_end_id >= c.semantic_begin_id && c.im_end_id <= c.semantic_end_id;
+  if (!im_inside && c.im_end_id < c.semantic_begin_id) ids.push_back(c.im_end_id);
+  for (int v = c.semantic_begin_id; v <= c.semantic_end_id; ++v) ids.push_back(v);
+  if (!im_inside && c.im_end_id > c.semantic_end_id) ids.push_back(c.im_end_id);
+  ids.resize(h->n_live_pad, 0);
+  FMI_CHECK_HIP(hipMemcpyAsync(h->live_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK(launch_pack_rows_gather(h->emb, h->live_ids, h->head_live, h->n_live, h->n_live_pad, c.dim, s));
+  // RoPE tables (llama.py:1004-1023) unless the host supplied torch-built ones
+  auto build_rope = [&](bf16_t* dst, int seq, int D) -> int {
+    std::vector<bf16_t> tab((size_t)seq * D);
+    for (int k = 0; k < D / 2; ++k) {
+      const float freq = 1.0f / powf(c.rope_base, (float)(2 * k) / (float)D);
+      for (int p = 0; p < seq; ++p) {
+        const float ang = (float)p * freq;
+        tab[((size_t)p * (D / 2) + k) * 2 + 0] = f2bf(cosf(ang));
+        tab[((size_t)p * (D / 2) + k) * 2 + 1] = f2bf(sinf(ang));
+      }
+    }
+    FMI_CHECK_HIP(hipMemcpyAsync(dst, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, s));
+    FMI_CHECK_HIP(hipStreamSynchronize(s));
+    return FMI_OK;
+  };
+  if (!h->rope_loaded) FMI_CHECK(build_rope(h->rope, c.max_seq_len, c.head_dim));
+  if (!h->fast_rope_loaded) FMI_CHECK(build_rope(h->fast_rope, c.num_codebooks, c.fast_head_dim));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  h->ready = true;
+  return sync_out(h, stream);
+}
+
+int fmi_dualar_weights_ready(fmi_dualar* h) {
+  FMI_REQUIRE(h, "null handle");
+  h->ready = true;
+  return FMI_OK;
+}
+
+int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_REQUIRE(max_batch >= 1 && max_seq_len >= 1, "bad cache size");
+  FMI_REQUIRE(max_seq_len <= h->cfg.max_seq_len, "max_seq_len %d exceeds config.max_seq_len %d (RoPE table)",
+              max_seq_len, h->cfg.max_seq_len);
+  if (h->max_batch >= max_batch && h->max_seq >= max_seq_len) return FMI_OK;  // llama.py:310-311
+  FMI_REQUIRE(h->max_batch == 0, "caches can only be set up once per handle");
+  const fmi_dualar_config& c = h->cfg;
+  const Dims &s = h->slow, &f = h->fast;
+  h->max_batch = max_batch;
+  h->max_seq = max_seq_len;
+  h->max_pages = cdiv(max_seq_len, KV_PAGE);
+  h->n_pages = h->max_pages * max_batch;
+  h->max_frames = max_seq_len;
+  const int ncb1 = c.num_codebooks + 1;
+  for (int i = 0; i < c.n_layer; ++i) {
+    bf16_t *k, *v;
+    FMI_CHECK(dev_alloc(&k, (int64_t)h->n_pages * s.KVH * KV_PAGE * s.D));
+    FMI_CHECK(dev_alloc(&v, (int64_t)h->n_pages * s.KVH * KV_PAGE * s.D));
+    h->kpool.push_back(k);
+    h->vpool.push_back(v);
+  }
+  for (int i = 0; i < c.n_fast_layer; ++i) {
+    bf16_t *k, *v;
+    FMI_CHECK(dev_alloc(&k, (int64_t)max_batch * f.KVH * c.num_codebooks * f.D));
+    FMI_CHECK(dev_alloc(&v, (int64_t)max_batch * f.KVH * c.num_codebooks * f.D));
+    h->fkc.push_back(k);
+    h->fvc.push_back(v);
+  }
+  SlotState& st = h->st;
+  st.max_pages = h->max_pages;
+  st.max_frames = h->max_frames;
+  st.ncb1 = ncb1;
+  FMI_CHECK(dev_alloc(&st.pos, max_batch));
+  FMI_CHECK(dev_alloc(&st.frame, max_batch));
+  FMI_CHECK(dev_alloc(&st.done, max_batch));
+  FMI_CHECK(dev_alloc(&st.limit, max_batch));
+  FMI_CHECK(dev_alloc(&st.cur, (int64_t)max_batch * ncb1));
+  FMI_CHECK(dev_alloc(&st.window, (int64_t)max_batch * ncb1 * RAS_WIN));
+  FMI_CHECK(dev_alloc(&st.out, (int64_t)max_batch * h->max_frames * ncb1));
+  FMI_CHECK(dev_alloc(&st.temperature, max_batch));
+  FMI_CHECK(dev_alloc(&st.top_p, max_batch));
+  FMI_CHECK(dev_alloc(&st.top_k, max_batch));
+  FMI_CHECK(dev_alloc(&st.seed, max_batch));
+  FMI_CHECK(dev_alloc(&st.use_ras, max_batch));
+  FMI_CHECK(dev_alloc(&st.block_table, (int64_t)max_batch * h->max_pages));
+  FMI_CHECK(dev_alloc(&h->hn, (int64_t)max_batch * c.dim));
+  FMI_CHECK(dev_alloc(&h->xl, (int64_t)max_batch * c.dim));
+  FMI_CHECK(dev_alloc(&h->xf, (int64_t)max_batch * c.fast_dim));
+  FMI_CHECK(dev_alloc(&h->logits, (int64_t)max_batch * h->n_live_pad));
+  FMI_CHECK(dev_alloc(&h->flogits, (int64_t)max_batch * c.codebook_size));
+  FMI_CHECK(dev_alloc(&h->ftrace, (int64_t)max_batch * c.num_codebooks * c.codebook_size));
+  h->free_pages.clear();
+  for (int p = h->n_pages - 1; p >= 0; --p) h->free_pages.push_back(p);
+  h->slot_pages.assign(max_batch, {});
+  return ensure_rows(h, max_batch);
+}
+
+int fmi_dualar_release(fmi_dualar* h, int slot) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK(check_slot(h, slot));
+  for (int p : h->slot_pages[slot]) h->free_pages.push_back(p);
+  h->slot_pages[slot].clear();
+  return FMI_OK;
+}
+
+static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int32_t* tokens_dev, const int32_t* lens,
+                        const int32_t* max_new, const fmi_sampling* samp, int frame_index, hipStream_t s) {
+  const fmi_dualar_config& c = h->cfg;
+  int rows = 0;
+  for (int i = 0; i < n; ++i) {
+    FMI_CHECK(check_slot(h, slot_ids[i]));
+    FMI_REQUIRE(lens[i] >= 1, "empty prompt for slot %d", slot_ids[i]);
+    if (lens[i] >= h->max_seq)  // inference.py:263-266
+      return set_error(FMI_EINVAL, "Input sequence length %d exceeds max_seq_len %d", lens[i], h->max_seq);
+    rows += lens[i];
+  }
+  FMI_CHECK(ensure_rows(h, std::max(rows, h->max_batch)));
+  std::vector<int32_t> row_slot(rows), row_pos(rows), last(n), slots(n);
+  int r = 0;
+  for (int i = 0; i < n; ++i) {
+    int mn = max_new[i];
+    if (mn <= 0 || lens[i] + mn > h->max_seq) mn = h->max_seq - lens[i];  // inference.py:268-275
+    const int limit = lens[i] + mn - 1;
+    FMI_CHECK(reserve_pages(h, slot_ids[i], std::max(limit, lens[i])));
+    FMI_CHECK(set_slot(h, slot_ids[i], lens[i], frame_index, limit, samp[i], frame_index == 0));
+    for (int t = 0; t < lens[i]; ++t, ++r) {
+      row_slot[r] = slot_ids[i];
+      row_pos[r] = t;
+    }
+    last[i] = r - 1;
+    slots[i] = slot_ids[i];
+  }
+  Workspace& ws = h->ws;
+  FMI_CHECK_HIP(hipMemcpyAsync(ws.row_slot, row_slot.data(), rows * 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK_HIP(hipMemcpyAsync(ws.row_pos, row_pos.data(), rows * 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK_HIP(hipMemcpyAsync(ws.last_rows, last.data(), n * 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+  h->launches = 0;
+  EmbedArgs e{};
+  e.emb = h->emb; e.cb_emb = h->cb_emb; e.tokens = tokens_dev; e.row_slot = nullptr; e.out = ws.x; e.rows = rows;
+  e.dim = c.dim; e.ncb = c.num_codebooks; e.cbs = c.codebook_size; e.sem_begin = c.semantic_begin_id;
+  e.sem_end = c.semantic_end_id; e.scale = c.scale_codebook_embeddings;
+  FMI_CHECK(launch_embed(e, s));
+  for (int i = 0; i < c.n_layer; ++i) FMI_CHECK(block_slow(h, h->L[i], i, ws.x, rows, ws.row_slot, ws.row_pos, s));
+  // llama.py:447-448: only the last position of each utterance feeds the head
+  FMI_CHECK(launch_gather_rows(ws.x, c.dim, ws.last_rows, h->xl, c.dim, n, c.dim, s));
+  // the tail addresses slots through row_slot[0..n)
+  FMI_CHECK_HIP(hipMemcpyAsync(ws.row_slot, slots.data(), n * 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  return tail(h, h->xl, n, ws.row_slot, s);
+}
+
+int fmi_dualar_prefill(fmi_dualar* h, int n, const int32_t* slot_ids, const int32_t* tokens_dev, const int32_t* lens,
+                       const int32_t* max_new, const fmi_sampling* samp, void* stream) {
+  FMI_REQUIRE(h && slot_ids && tokens_dev && lens && max_new && samp, "null argument");
+  FMI_REQUIRE(h->ready, "weights not ready");
+  FMI_REQUIRE(n >= 1 && n <= h->max_batch, "n=%d out of range", n);
+  FMI_CHECK(sync_in(h, stream));
+  FMI_CHECK(prefill_impl(h, n, slot_ids, tokens_dev, lens, max_new, samp, 0, h->stream));
+  return sync_out(h, stream);
+}
+
+int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frames, void* stream) {
+  FMI_REQUIRE(h && slot_ids, "null argument");
+  FMI_REQUIRE(h->ready, "weights not ready");
+  FMI_REQUIRE(n >= 1 && n <= h->max_batch, "n=%d out of range", n);
+  for (int i = 0; i < n; ++i) FMI_CHECK(check_slot(h, slot_ids[i]));
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, slot_ids, n * 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  hipGraphExec_t exec = nullptr;
+  if (h->use_graph && !h->trace) {
+    auto it = h->graphs.find(n);
+    if (it == h->graphs.end()) {
+      hipGraph_t g = nullptr;
+      FMI_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      int rc = decode_frame(h, n, s);
+      hipError_t e = hipStreamEndCapture(s, &g);
+      if (rc != FMI_OK) return rc;
+      FMI_CHECK_HIP(e);
+      FMI_CHECK_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+      FMI_CHECK_HIP(hipGraphDestroy(g));
+      h->graphs[n] = exec;
+    } else {
+      exec = it->second;
+    }
+  }
+  FMI_CHECK_HIP(hipEventRecord(h->ev_t0, s));
+  for (int f = 0; f < n_frames; ++f) {
+    if (exec) FMI_CHECK_HIP(hipGraphLaunch(exec, s));
+    else FMI_CHECK(decode_frame(h, n, s));
+  }
+  FMI_CHECK_HIP(hipEventRecord(h->ev_t1, s));
+  return sync_out(h, stream);
+}
+
+int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_frame) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK_HIP(hipEventSynchronize(h->ev_t1));
+  float t = 0.f;
+  FMI_CHECK_HIP(hipEventElapsedTime(&t, h->ev_t0, h->ev_t1));
+  if (ms) *ms = t;
+  if (launches_per_frame) *launches_per_frame = h->launches;
+  return FMI_OK;
+}
+
+int fmi_dualar_read(fmi_dualar* h, int slot, int32_t* out_host, int max_frames, int* n_frames_out, int* done_out,
+                    void* stream) {
+  FMI_REQUIRE(h && out_host && n_frames_out, "null argument");
+  FMI_CHECK(check_slot(h, slot));
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  int32_t nf = 0, dn = 0;
+  FMI_CHECK_HIP(hipMemcpyAsync(&nf, h->st.frame + slot, 4, hipMemcpyDeviceToHost, s));
+  FMI_CHECK_HIP(hipMemcpyAsync(&dn, h->st.done + slot, 4, hipMemcpyDeviceToHost, s));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  const int n = std::min(nf, max_frames);
+  if (n > 0)
+    FMI_CHECK_HIP(hipMemcpyAsync(out_host, h->st.out + (int64_t)slot * h->st.max_frames * h->st.ncb1,
+                                 (size_t)n * h->st.ncb1 * 4, hipMemcpyDeviceToHost, s));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  *n_frames_out = n;
+  if (done_out) *done_out = dn;
+  return FMI_OK;
+}
+
+int fmi_dualar_poll_done(fmi_dualar* h, int n, const int32_t* slot_ids, int32_t* done_host, void* stream) {
+  FMI_REQUIRE(h && slot_ids && done_host, "null argument");
+  FMI_CHECK(sync_in(h, stream));
+  std::vector<int32_t> all(h->max_batch);
+  FMI_CHECK_HIP(hipMemcpyAsync(all.data(), h->st.done, h->max_batch * 4, hipMemcpyDeviceToHost, h->stream));
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) {
+    FMI_CHECK(check_slot(h, slot_ids[i]));
+    done_host[i] = all[slot_ids[i]];
+  }
+  return FMI_OK;
+}
+
+int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int pos0, const fmi_sampling* samp,
+                    const int32_t* prev_dev, int32_t frame_index, int32_t* out_dev, void* stream) {
+  FMI_REQUIRE(h && x_dev && samp && out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "weights not ready");
+  FMI_CHECK(check_slot(h, slot));
+  FMI_REQUIRE(S >= 1, "S must be >= 1");
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  const int ncb1 = h->st.ncb1;
+  fmi_sampling sp = *samp;
+  sp.use_ras = prev_dev != nullptr;
+  if (S > 1 || pos0 == 0) {
+    FMI_REQUIRE(pos0 == 0, "multi-token call must start at position 0");
+    const int32_t len = S, mn = 0;
+    FMI_CHECK(prefill_impl(h, 1, &slot, x_dev, &len, &mn, &sp, frame_index, s));
+  } else {
+    FMI_REQUIRE(pos0 < h->max_seq, "position %d beyond max_seq_len %d", pos0, h->max_seq);
+    FMI_CHECK(reserve_pages(h, slot, h->max_seq));
+    FMI_CHECK(set_slot(h, slot, pos0, frame_index, h->max_seq, sp, false));
+    FMI_CHECK_HIP(hipMemcpyAsync(h->st.cur + (int64_t)slot * ncb1, x_dev, ncb1 * 4, hipMemcpyDeviceToDevice, s));
+    FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
+    FMI_CHECK_HIP(hipStreamSynchronize(s));
+    if (prev_dev)
+      FMI_CHECK_HIP(hipMemcpyAsync(h->st.window + (int64_t)slot * ncb1 * RAS_WIN, prev_dev,
+                                   (size_t)ncb1 * RAS_WIN * 4, hipMemcpyDeviceToDevice, s));
+    FMI_CHECK(decode_frame(h, 1, s));
+  }
+  FMI_CHECK_HIP(hipMemcpyAsync(out_dev, h->st.cur + (int64_t)slot * ncb1, ncb1 * 4, hipMemcpyDeviceToDevice, s));
+  return sync_out(h, stream);
+}
+
+int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* ld_logits, void** live_ids,
+                          void** hidden, void** fast_logits) {
+  FMI_REQUIRE(h, "null handle");
+  if (slow_logits) *slow_logits = h->logits;
+  if (n_live) *n_live = h->n_live;
+  if (ld_logits) *ld_logits = h->n_live_pad;
+  if (live_ids) *live_ids = h->live_ids;
+  if (hidden) *hidden = h->hn;
+  if (fast_logits) *fast_logits = h->flogits;
+  return FMI_OK;
+}
+
+int fmi_dualar_set_trace(fmi_dualar* h, int enable, void** fast_trace) {
+  FMI_REQUIRE(h, "null handle");
+  h->trace = enable != 0;
+  if (fast_trace) *fast_trace = h->ftrace;
+  return FMI_OK;
+}
+
+int fmi_dualar_set_ignore_eos(fmi_dualar* h, int enable) {
+  FMI_REQUIRE(h, "null handle");
+  if (h->ignore_eos != (enable != 0)) {
+    hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+  }
+  h->ignore_eos = enable != 0;
+  return FMI_OK;
+}
+
+int fmi_dualar_set_graph(fmi_dualar* h, int enable) {
+  FMI_REQUIRE(h, "null handle");
+  h->use_graph = enable != 0;
+  return FMI_OK;
+}
+
+// ------------------------------------------------------------------------- op-level entry points
+
+int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_dev, const void* residual_dev,
+                       void* out_dev, int M, int N, int K, float eps, int epilogue, int force_path, void* stream) {
+  FMI_REQUIRE(x_dev && w_dev && out_dev, "null argument");
+  FMI_REQUIRE(epilogue >= 0 && epilogue <= 2, "bad epilogue");
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t* packed = nullptr;
+  bf16_t* xn = nullptr;
+  FMI_CHECK_HIP(hipMalloc((void**)&packed, (size_t)N * K * 2));
+  int rc;
+  const int n_out = (epilogue == EPI_SILU) ? N / 2 : N;
+  if (epilogue == EPI_SILU) {
+    rc = launch_pack_weight((const bf16_t*)w_dev, packed, N / 2, K, 1, s);
+    if (rc == FMI_OK) rc = launch_pack_weight((const bf16_t*)w_dev + (int64_t)(N / 2) * K, packed, N / 2, K, 2, s);
+  } else {
+    rc = launch_pack_weight((const bf16_t*)w_dev, packed, N, K, 0, s);
+  }
+  LinearArgs a{};
+  a.wp = packed; a.x = (const bf16_t*)x_dev; a.ldx = K; a.norm_w = (const bf16_t*)norm_w_dev; a.eps = eps;
+  a.res = (const bf16_t*)residual_dev; a.ldr = n_out; a.out = (bf16_t*)out_dev; a.ldo = n_out; a.M = M; a.N = N;
+  a.K = K; a.epi = epilogue;
+  const bool skinny = force_path == 1 || (force_path == 0 && M <= 16);
+  if (rc == FMI_OK) {
+    if (skinny) {
+      rc = launch_linear_skinny(a, s);
+    } else {
+      if (a.norm_w) {
+        if (hipMalloc((void**)&xn, (size_t)M * K * 2) != hipSuccess) rc = set_error(FMI_EHIP, "hipMalloc");
+        if (rc == FMI_OK) rc = launch_rmsnorm_rows(a.x, K, a.norm_w, eps, xn, K, M, K, s);
+        a.x = xn;
+        a.norm_w = nullptr;
+      }
+      if (rc == FMI_OK) rc = launch_linear_tiled(a, s);
+    }
+  }
+  hipStreamSynchronize(s);
+  hipFree(packed);
+  if (xn) hipFree(xn);
+  return rc;
+}
+
+int fmi_op_sample(const void* logits_dev, int B, int n, int ld, const int32_t* ids_dev, const fmi_sampling* samp,
+                  int frame, int draw, const int32_t* prev_dev, int sem_begin, int sem_end, int32_t* out_dev,
+                  void* stream) {
+  FMI_REQUIRE(logits_dev && samp && out_dev, "null argument");
+  SampleArgs a{};
+  a.logits = (const bf16_t*)logits_dev; a.B = B; a.n = n; a.ld = ld; a.ids = ids_dev; a.row_slot = nullptr;
+  a.mode = 2; a.sem_begin = sem_begin; a.sem_end = sem_end; a.temperature = rbf(samp->temperature);
+  a.top_p = rbf(samp->top_p); a.top_k = samp->top_k; a.seed = samp->seed; a.frame = frame; a.draw = draw;
+  a.prev = prev_dev; a.out_tok = out_dev; a.xf = nullptr;
+  return launch_sample(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// dualar_kernels.h -- launch wrappers of the Dual-AR decode kernels (dualar_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace fmi {
+
+constexpr int KV_PAGE = 64;       // tokens per KV page
+constexpr int RAS_WIN = 10;       // inference.py:49
+constexpr int SAMPLER_MAXK = 1024;
+
+enum Epilogue { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SILU = 2 };
+
+// Per-slot generation state, structure-of-arrays in device memory.
+struct SlotState {
+  int32_t* pos;        // [S] next input position (= tokens already in the KV cache)
+  int32_t* frame;      // [S] frames generated so far (0 while the prefill frame is being built)
+  int32_t* done;       // [S] 1 after <|im_end|>, 2 after the reservation ran out
+  int32_t* limit;      // [S] max position (exclusive) the slot's pages cover
+  int32_t* cur;        // [S][1+ncb] tokens of the last completed frame (next slow input)
+  int32_t* window;     // [S][1+ncb][RAS_WIN]
+  int32_t* out;        // [S][max_frames][1+ncb]
+  float* temperature;  // [S] bf16-rounded
+  float* top_p;        // [S] bf16-rounded
+  int32_t* top_k;      // [S]
+  uint32_t* seed;      // [S]
+  int32_t* use_ras;    // [S]
+  int32_t* block_table;  // [S][max_pages]
+  int max_pages, max_frames, ncb1;
+};
+
+// Weight tile packing: row-major (N,K) bf16 -> [N/16][K/32][64 lanes][8] MFMA fragments.
+// interleave: 0 identity; 1/2 = w1/w3 halves of the SwiGLU pair, 16-row blocks alternating.
+int launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int interleave, hipStream_t s);
+// gather `n` rows listed in ids_dev (int32 vocab ids, on device) then pack (live LM-head rows).
+int launch_pack_rows_gather(const bf16_t* src, const int32_t* ids_dev, bf16_t* dst, int n, int n_pad,
+                            int K, hipStream_t s);
+int launch_rope_table(bf16_t* dst, int seq_len, int head_dim, float base, hipStream_t s);
+
+struct LinearArgs {
+  const bf16_t* wp;        // packed weights
+  const bf16_t* x;         // [M][ldx]
+  int ldx;
+  const bf16_t* norm_w;    // fused RMSNorm weight (skinny path only) or nullptr
+  float eps;
+  const bf16_t* res;       // residual [M][ldr] for EPI_RESIDUAL
+  int ldr;
+  bf16_t* out;             // [M][ldo]
+  int ldo;
+  int M, N, K;             // N = packed rows (2*ffn for EPI_SILU)
+  int epi;
+};
+int launch_linear_skinny(const LinearArgs& a, hipStream_t s);  // M <= 16
+int launch_linear_tiled(const LinearArgs& a, hipStream_t s);   // any M, no fused norm
+int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf16_t* out, int ldo,
+                        int M, int K, hipStream_t s);
+
+struct EmbedArgs {
+  const bf16_t* emb;      // [V][dim]
+  const bf16_t* cb_emb;   // [ncb*cbs][dim]
+  const int32_t* tokens;  // rows x (1+ncb) when row_slot==nullptr, else SlotState.cur
+  const int32_t* row_slot;
+  bf16_t* out;            // [rows][dim]
+  int rows, dim, ncb, cbs, sem_begin, sem_end, scale;
+};
+int launch_embed(const EmbedArgs& a, hipStream_t s);
+int launch_gather_rows(const bf16_t* src, int ld_src, const int32_t* row_idx, bf16_t* dst, int ld_dst,
+                       int rows, int cols, hipStream_t s);
+
+struct AttnArgs {
+  const bf16_t* qkv;      // [rows][(H+2KVH)*D]
+  bf16_t* q;              // [rows][H*D] scratch (normed+roped q)
+  bf16_t* out;            // [rows][H*D]
+  bf16_t* kpool;          // [pages][KVH][KV_PAGE][D]
+  bf16_t* vpool;
+  const bf16_t* qnw;      // q_norm weight or nullptr
+  const bf16_t* knw;
+  const bf16_t* rope;     // [max_seq][D/2][2]
+  const int32_t* row_slot;  // [rows]
+  const int32_t* row_pos;   // [rows] or nullptr -> SlotState.pos[slot]
+  const int32_t* block_table;
+  const int32_t* slot_pos;
+  int max_pages;
+  int rows, H, KVH, D;
+  float eps;
+};
+int launch_attn_prep(const AttnArgs& a, hipStream_t s);
+int launch_attn(const AttnArgs& a, hipStream_t s);
+
+struct FastAttnArgs {
+  const bf16_t* qkv;   // [B][(H+2KVH)*D]
+  bf16_t* out;         // [B][H*D]
+  bf16_t* kc;          // [slots][KVH][ncb][D]
+  bf16_t* vc;
+  const bf16_t* qnw;
+  const bf16_t* knw;
+  const bf16_t* rope;  // [ncb][D/2][2]
+  const int32_t* row_slot;
+  int B, H, KVH, D, ncb, pos;
+  float eps;
+};
+int launch_fast_attn(const FastAttnArgs& a, hipStream_t s);
+
+struct SampleArgs {
+  const bf16_t* logits;   // [B][ld]
+  int B, n, ld;
+  const int32_t* ids;     // row index -> vocab id (nullptr = identity)
+  const int32_t* row_slot;  // nullptr = identity
+  SlotState st;
+  int mode;               // 0 slow (2 draws + RAS + cb0), 1 fast codebook, 2 bare op (tests)
+  int cb;                 // fast: codebook index (1..ncb-1)
+  int sem_begin, sem_end, im_end, cbs;
+  const bf16_t* fast_emb; // [cbs][fdim] gathered into xf after the draw
+  bf16_t* xf;             // [B][fdim]
+  int fdim;
+  // mode 2 (op-level): explicit parameters
+  float temperature, top_p;
+  int top_k;
+  uint32_t seed;
+  int frame, draw;
+  const int32_t* prev;    // [B][RAS_WIN] or nullptr
+  int32_t* out_tok;       // [B]
+};
+int launch_sample(const SampleArgs& a, hipStream_t s);
+
+}  // namespace fmi

@@ -1,0 +1,1055 @@
+// dualar_kernels.hip -- hand-written gfx950 kernels of the Dual-AR decode step.
+//
+// Reference semantics (fish_speech/models/text2semantic/):
+//   embed            llama.py:400-420        RMSNorm          llama.py:990-1001
+//   linear layers    llama.py:895,946,979-987 (bf16 in, fp32 accumulate, bf16 out)
+//   q/k head norm    llama.py:862-864,901-903 RoPE            llama.py:1004-1038
+//   KV cache         llama.py:196-214        slow attention   llama.py:928-934 (MATH backend)
+//   fast attention   llama.py:948-976        sampler          inference.py:43-93,118-144
+//
+// Design notes (MI355X): the decode step is a weight-streaming problem (15.5 GB of bf16 weights
+// per frame shared by all utterances, arithmetic intensity ~= batch).  Weights are pre-tiled at
+// load time into MFMA-fragment order so that ONE wave instruction (global_load_dwordx4, 64 lanes)
+// fetches ONE contiguous 1 KiB 16x32 tile that feeds v_mfma_f32_16x16x32_bf16 directly -- no LDS
+// round trip for operands that are used once (guide: "GEMV / M<=16: load straight to VGPRs").
+// The batch sits in the MFMA N dimension (16 columns), so results are batch-invariant:
+// an utterance's numbers do not depend on which other utterances share the step.
+#include "dualar_kernels.h"
+
+namespace fmi {
+
+// =====================================================================================
+// weight packing
+// =====================================================================================
+
+__device__ inline int64_t packed_index(int n, int k, int KT) {
+  // tile (n/16, k/32); inside: lane = (k%32/8)*16 + n%16, element k%8
+  int lane = ((k & 31) >> 3) * 16 + (n & 15);
+  return ((int64_t)(n >> 4) * KT + (k >> 5)) * 512 + lane * 8 + (k & 7);
+}
+
+__global__ void pack_weight_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K,
+                                   int interleave) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 elements
+  int64_t total = (int64_t)N * K / 8;
+  if (idx >= total) return;
+  int kc = (int)(idx % (K / 8));
+  int n = (int)(idx / (K / 8));
+  int nd = n;
+  if (interleave == 1) nd = (n >> 4) * 32 + (n & 15);
+  if (interleave == 2) nd = (n >> 4) * 32 + 16 + (n & 15);
+  uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)n * K + kc * 8);
+  *reinterpret_cast<uint4*>(dst + packed_index(nd, kc * 8, K / 32)) = v;
+}
+
+int launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int interleave, hipStream_t s) {
+  FMI_REQUIRE(N % 16 == 0 && K % 32 == 0, "pack_weight: N=%d must be a multiple of 16 and K=%d of 32", N, K);
+  int64_t total = (int64_t)N * K / 8;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, N, K,
+                     interleave);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+__global__ void pack_rows_gather_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ ids,
+                                        bf16_t* __restrict__ dst, int n, int n_pad, int K) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)n_pad * K / 8;
+  if (idx >= total) return;
+  int kc = (int)(idx % (K / 8));
+  int r = (int)(idx / (K / 8));
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (r < n) v = *reinterpret_cast<const uint4*>(src + (int64_t)ids[r] * K + kc * 8);
+  *reinterpret_cast<uint4*>(dst + packed_index(r, kc * 8, K / 32)) = v;
+}
+
+int launch_pack_rows_gather(const bf16_t* src, const int32_t* ids_dev, bf16_t* dst, int n, int n_pad, int K,
+                            hipStream_t s) {
+  FMI_REQUIRE(n_pad % 16 == 0 && K % 32 == 0, "pack_rows_gather: bad shape");
+  int64_t total = (int64_t)n_pad * K / 8;
+  hipLaunchKernelGGL(pack_rows_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ids_dev,
+                     dst, n, n_pad, K);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// RoPE table, llama.py:1004-1023: angle = pos * base^(-2k/D) in fp32, cos/sin rounded to bf16.
+// The table is built on the HOST with the same libm family torch uses on CPU (cosf/sinf of a
+// fp32 angle) so that the bf16-rounded entries agree with the reference's; see dualar.hip.
+int launch_rope_table(bf16_t*, int, int, float, hipStream_t) { return FMI_OK; }
+
+// =====================================================================================
+// embedding (llama.py:400-420)
+// =====================================================================================
+
+__global__ void embed_kernel(EmbedArgs a) {
+  int r = blockIdx.x;
+  const int32_t* tok = a.row_slot ? a.tokens + (int64_t)a.row_slot[r] * (a.ncb + 1)
+                                  : a.tokens + (int64_t)r * (a.ncb + 1);
+  int t0 = tok[0];
+  bool sem = (t0 >= a.sem_begin) && (t0 <= a.sem_end);
+  const float inv = sqrtf((float)(a.ncb + 1));  // x / math.sqrt(ncb+1), divisor rounded to fp32
+  for (int d = threadIdx.x; d < a.dim; d += blockDim.x) {
+    // torch.stack(embeds).sum(dim=1) on bf16: fp32 accumulation, one rounding
+    float vq = 0.f;
+    for (int i = 0; i < a.ncb; ++i) vq += bf2f(a.cb_emb[(int64_t)(tok[i + 1] + i * a.cbs) * a.dim + d]);
+    float vqr = sem ? rbf(vq) : 0.f;
+    float x = rbf(bf2f(a.emb[(int64_t)t0 * a.dim + d]) + vqr);
+    if (a.scale && sem) x = rbf(x / inv);
+    a.out[(int64_t)r * a.dim + d] = f2bf(x);
+  }
+}
+
+int launch_embed(const EmbedArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel, dim3(a.rows), dim3(256), 0, s, a);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, int ld_src, const int32_t* __restrict__ row_idx,
+                                   bf16_t* __restrict__ dst, int ld_dst, int cols) {
+  int r = blockIdx.x;
+  const bf16_t* s = src + (int64_t)row_idx[r] * ld_src;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8)
+    *reinterpret_cast<uint4*>(dst + (int64_t)r * ld_dst + c) = *reinterpret_cast<const uint4*>(s + c);
+}
+
+int launch_gather_rows(const bf16_t* src, int ld_src, const int32_t* row_idx, bf16_t* dst, int ld_dst, int rows,
+                       int cols, hipStream_t s) {
+  FMI_REQUIRE(cols % 8 == 0, "gather_rows: cols %% 8");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, s, src, ld_src, row_idx, dst, ld_dst, cols);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// =====================================================================================
+// RMSNorm helpers (llama.py:990-1001): fp32 normalise -> cast -> * weight (bf16)
+// =====================================================================================
+
+// sum of squares of one row, one wave, fixed order (lane-strided 16-byte chunks, then xor tree).
+__device__ inline float row_rstd(const bf16_t* __restrict__ x, int K, float eps, int lane) {
+  float ss = 0.f;
+  for (int c = lane * 8; c < K; c += 64 * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(x + c);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = bf2f(e[j]);
+      ss += f * f;
+    }
+  }
+  ss = wave_sum(ss);
+  return rsqrtf(ss / (float)K + eps);
+}
+
+__device__ inline bf16x8 norm_frag(uint4 xv, uint4 wv, float rstd) {
+  const bf16_t* xe = reinterpret_cast<const bf16_t*>(&xv);
+  const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float n = rbf(bf2f(xe[j]) * rstd);
+    o[j] = (short)f2bf(n * bf2f(we[j]));
+  }
+  return o;
+}
+
+__global__ void rmsnorm_rows_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w, float eps,
+                                    bf16_t* __restrict__ out, int ldo, int M, int K) {
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int r = blockIdx.x * 4 + wave;
+  if (r >= M) return;
+  const bf16_t* xr = x + (int64_t)r * ldx;
+  float rstd = row_rstd(xr, K, eps, lane);
+  for (int c = lane * 8; c < K; c += 64 * 8) {
+    uint4 xv = *reinterpret_cast<const uint4*>(xr + c);
+    uint4 wv = *reinterpret_cast<const uint4*>(w + c);
+    bf16x8 o = norm_frag(xv, wv, rstd);
+    *reinterpret_cast<bf16x8*>(out + (int64_t)r * ldo + c) = o;
+  }
+}
+
+int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf16_t* out, int ldo, int M, int K,
+                        hipStream_t s) {
+  FMI_REQUIRE(K % 8 == 0, "rmsnorm: K %% 8");
+  hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, w, eps, out, ldo, M, K);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// =====================================================================================
+// skinny linear (M <= 16): weight-streaming MFMA GEMV
+// =====================================================================================
+//
+// Work-group = WAVES waves, owns TILES 16-row weight tiles over the whole K; wave w owns the k-tiles
+// [w*KT/WAVES, (w+1)*KT/WAVES).  Per k-tile a lane issues one 16-byte weight load (the wave: one
+// contiguous 1 KiB tile) and one 16-byte activation load (L2-resident), then one MFMA per tile.
+// Split-K partials meet in LDS and are summed in wave order (deterministic).
+
+__device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+template <int WAVES, int EPI, bool NORM, int UNR>
+__global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a) {
+  constexpr int TILES = (EPI == EPI_SILU) ? 2 : 1;
+  __shared__ float red[WAVES][TILES][256];
+  __shared__ float s_rstd[16];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = lane & 15, g = lane >> 4;
+  const int KT = a.K >> 5;
+  const int tile0 = blockIdx.x * TILES;
+  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
+
+  const int kbeg = (int)((int64_t)wave * KT / WAVES), kend = (int)((int64_t)(wave + 1) * KT / WAVES);
+
+  float rstd = 0.f;
+  if (NORM) {
+    for (int r = wave; r < a.M; r += WAVES) {
+      float v = row_rstd(a.x + (int64_t)r * a.ldx, a.K, a.eps, lane);
+      if (lane == 0) s_rstd[r] = v;
+    }
+    __syncthreads();
+    if (b < a.M) rstd = s_rstd[b];
+  }
+
+  const bool bvalid = b < a.M;
+  const bf16_t* xrow = a.x + (int64_t)(bvalid ? b : 0) * a.ldx + g * 8;
+  const bf16_t* nrow = NORM ? a.norm_w + g * 8 : nullptr;
+
+  f32x4 acc[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int kt = kbeg;
+  for (; kt + UNR <= kend; kt += UNR) {
+    u32x4 wv[TILES][UNR];
+    uint4 xv[UNR];
+    uint4 nv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+        wv[t][u] = __builtin_nontemporal_load(wp + ((int64_t)(tile0 + t) * KT + kt + u) * 64 + lane);
+      xv[u] = bvalid ? *reinterpret_cast<const uint4*>(xrow + (kt + u) * 32) : make_uint4(0, 0, 0, 0);
+      if (NORM) nv[u] = *reinterpret_cast<const uint4*>(nrow + (kt + u) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      bf16x8 xb;
+      if (NORM) xb = norm_frag(xv[u], nv[u], rstd);
+      else xb = *reinterpret_cast<bf16x8*>(&xv[u]);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[t][u]), xb, acc[t], 0, 0, 0);
+    }
+  }
+  for (; kt < kend; ++kt) {
+    uint4 xv = bvalid ? *reinterpret_cast<const uint4*>(xrow + kt * 32) : make_uint4(0, 0, 0, 0);
+    bf16x8 xb;
+    if (NORM) {
+      uint4 nv = *reinterpret_cast<const uint4*>(nrow + kt * 32);
+      xb = norm_frag(xv, nv, rstd);
+    } else {
+      xb = *reinterpret_cast<bf16x8*>(&xv);
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      u32x4 wv = __builtin_nontemporal_load(wp + ((int64_t)(tile0 + t) * KT + kt) * 64 + lane);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[t], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[t];
+  __syncthreads();
+
+  if (tid < 256) {
+    const int bb = tid >> 4, r = tid & 15;  // consecutive threads -> consecutive output columns
+    if (bb < a.M) {
+      const int ridx = (((r >> 2) * 16) + bb) * 4 + (r & 3);
+      float v[TILES];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sacc += red[w][t][ridx];
+        v[t] = sacc;
+      }
+      if (EPI == EPI_STORE) {
+        a.out[(int64_t)bb * a.ldo + tile0 * 16 + r] = f2bf(v[0]);
+      } else if (EPI == EPI_RESIDUAL) {
+        const int n = tile0 * 16 + r;
+        a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + rbf(v[0]));
+      } else {  // SwiGLU: tile0 = gate rows, tile0+1 = up rows (llama.py:987)
+        const int n = blockIdx.x * 16 + r;
+        float gate = rbf(silu_f(rbf(v[0])));
+        float up = rbf(v[TILES - 1]);
+        a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
+      }
+    }
+  }
+}
+
+template <int WAVES, int UNR>
+static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
+  const bool norm = a.norm_w != nullptr;
+  const int tiles = (a.epi == EPI_SILU) ? 2 : 1;
+  dim3 grid(a.N / (16 * tiles)), block(WAVES * 64);
+#define FMI_LAUNCH(EPI_, NORM_) \
+  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR>), grid, block, 0, s, a)
+  if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH(EPI_STORE, true); else FMI_LAUNCH(EPI_STORE, false); }
+  else if (a.epi == EPI_RESIDUAL) { if (norm) FMI_LAUNCH(EPI_RESIDUAL, true); else FMI_LAUNCH(EPI_RESIDUAL, false); }
+  else { if (norm) FMI_LAUNCH(EPI_SILU, true); else FMI_LAUNCH(EPI_SILU, false); }
+#undef FMI_LAUNCH
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.M >= 1 && a.M <= 16, "linear_skinny: M=%d not in [1,16]", a.M);
+  FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0, "linear_skinny: bad shape N=%d K=%d", a.N, a.K);
+  if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_skinny: SwiGLU needs N %% 32");
+  const int KT = a.K / 32;
+  // split-K factor: enough waves in flight to cover HBM latency when there are few row tiles
+  const int ntile = a.N / 16;
+  if (ntile >= 512 || KT < 16) {
+    if (KT >= 16) return launch_skinny_t<4, 4>(a, s);
+    return launch_skinny_t<4, 1>(a, s);
+  }
+  if (KT >= 128) return launch_skinny_t<16, 4>(a, s);
+  if (KT >= 64) return launch_skinny_t<8, 4>(a, s);
+  return launch_skinny_t<4, 4>(a, s);
+}
+
+// =====================================================================================
+// tiled linear (any M; prefill): 128x128 block, 4 waves (2x2), each 64x64 = 4x4 MFMA tiles.
+// Operands go straight from global/L2 into fragments (weights are already fragment-ordered).
+// =====================================================================================
+
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_tiled_kernel(LinearArgs a) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int KT = a.K >> 5;
+  const int n_tile0 = blockIdx.x * 8 + wn * 4;  // 16-row weight tiles
+  const int m0 = blockIdx.y * 128 + wm * 64;
+  const int NT = a.N >> 4;
+  const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(a.wp);
+  const int mi = lane & 15, g = lane >> 4;
+
+  const bf16_t* xrow[4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    int m = m0 + tm * 16 + mi;
+    if (m >= a.M) m = a.M - 1;
+    xrow[tm] = a.x + (int64_t)m * a.ldx + g * 8;
+  }
+  int ntile[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) ntile[tn] = min(n_tile0 + tn, NT - 1);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = 0; kt < KT; ++kt) {
+    uint4 wv[4], xv[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) wv[tn] = wp[((int64_t)ntile[tn] * KT + kt) * 64 + lane];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) xv[tm] = *reinterpret_cast<const uint4*>(xrow[tm] + kt * 32);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[tn]),
+                                                              *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
+  }
+
+  // lane holds D[n = tile*16 + g*4 + j][m = tile*16 + mi]
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + tm * 16 + mi;
+    if (m >= a.M) continue;
+    if (EPI == EPI_SILU) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int nt_gate = n_tile0 + tp * 2;
+        if (nt_gate >= NT) continue;
+        const int n = (nt_gate >> 1) * 16 + g * 4;
+        bf16_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gate = rbf(silu_f(rbf(acc[tp * 2][tm][j])));
+          float up = rbf(acc[tp * 2 + 1][tm][j]);
+          o[j] = f2bf(gate * up);
+        }
+        *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        if (n_tile0 + tn >= NT) continue;
+        const int n = (n_tile0 + tn) * 16 + g * 4;
+        bf16_t o[4];
+        if (EPI == EPI_RESIDUAL) {
+          uint2 rv = *reinterpret_cast<const uint2*>(a.res + (int64_t)m * a.ldr + n);
+          const bf16_t* re = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(re[j]) + rbf(acc[tn][tm][j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[tn][tm][j]);
+        }
+        *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
+      }
+    }
+  }
+}
+
+int launch_linear_tiled(const LinearArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.norm_w == nullptr, "linear_tiled: fused norm not supported (use rmsnorm_rows)");
+  FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0 && a.ldo % 4 == 0, "linear_tiled: bad shape");
+  if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_tiled: SwiGLU needs N %% 32");
+  dim3 grid(cdiv(a.N / 16, 8), cdiv(a.M, 128)), block(256);
+  if (a.epi == EPI_STORE) hipLaunchKernelGGL(linear_tiled_kernel<EPI_STORE>, grid, block, 0, s, a);
+  else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL(linear_tiled_kernel<EPI_RESIDUAL>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(linear_tiled_kernel<EPI_SILU>, grid, block, 0, s, a);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// =====================================================================================
+// attention: prep (q/k head norm + RoPE + paged KV write), then attention over the cache
+// =====================================================================================
+
+// one wave per head; lane p owns the RoPE pair (2p, 2p+1)
+__global__ __launch_bounds__(256) void attn_prep_kernel(AttnArgs a) {
+  const int r = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = a.row_slot[r];
+  const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
+  const int D = a.D, H = a.H, KVH = a.KVH;
+  const int total = H + 2 * KVH;
+  const bf16_t* src = a.qkv + (int64_t)r * total * D;
+  const int page = a.block_table[(int64_t)slot * a.max_pages + pos / KV_PAGE];
+  const int off = pos % KV_PAGE;
+  for (int h = wave; h < total; h += 4) {
+    for (int p = lane; p < D / 2; p += 64) {
+      uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+      float x0 = bf2f((bf16_t)(raw & 0xffff)), x1 = bf2f((bf16_t)(raw >> 16));
+      bf16_t o0, o1;
+      if (h >= H + KVH) {  // value head: plain copy
+        o0 = (bf16_t)(raw & 0xffff);
+        o1 = (bf16_t)(raw >> 16);
+      } else {
+        const bf16_t* nw = (h < H) ? a.qnw : a.knw;
+        float y0 = x0, y1 = x1;
+        if (nw) {  // torch.nn.RMSNorm: fp32 normalise * weight, one cast (llama.py:862-864)
+          // NOTE: D/2 <= 64 so one pass of the loop covers the head; partial waves reduce zeros
+          float ss = wave_sum(x0 * x0 + x1 * x1);
+          float rstd = rsqrtf(ss / (float)D + a.eps);
+          y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(nw[2 * p])));
+          y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(nw[2 * p + 1])));
+        }
+        uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+        float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
+        // llama.py:1026-1038, separate fp32 mul / sub / add (no fused multiply-add)
+        o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
+        o1 = f2bf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
+      }
+      uint32_t packed = (uint32_t)o0 | ((uint32_t)o1 << 16);
+      if (h < H) {
+        *reinterpret_cast<uint32_t*>(a.q + ((int64_t)r * H + h) * D + 2 * p) = packed;
+      } else {
+        const int kh = (h < H + KVH) ? h - H : h - H - KVH;
+        bf16_t* pool = (h < H + KVH) ? a.kpool : a.vpool;
+        *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kh) * KV_PAGE + off) * D + 2 * p) = packed;
+      }
+    }
+  }
+}
+
+int launch_attn_prep(const AttnArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.D % 2 == 0 && a.D <= 128 && a.D >= 16, "attn_prep: head_dim=%d unsupported", a.D);
+  hipLaunchKernelGGL(attn_prep_kernel, dim3(a.rows), dim3(256), 0, s, a);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// grid (rows, KVH): one work-group handles the G query heads sharing one KV head.  LPT = D/8 lanes
+// share a token (16 bytes each, coalesced 2*D-byte rows); a wave covers 64/LPT tokens per step.
+// Online softmax per lane group; partial (m, l, acc) states are merged through LDS.
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  constexpr int LPT = D / 8, TPW = 64 / LPT, NP = 4 * TPW;
+  __shared__ float s_m[NP][G], s_l[NP][G];
+  __shared__ float s_acc[NP][G][D];
+  const int r = blockIdx.x, kvh = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPT, dl = lane % LPT;
+  const int slot = a.row_slot[r];
+  const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
+  const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
+  const float scale = 1.0f / sqrtf((float)D);
+
+  float q[G][8];
+#pragma unroll
+  for (int gq = 0; gq < G; ++gq) {
+    uint4 v = *reinterpret_cast<const uint4*>(a.q + ((int64_t)r * a.H + kvh * G + gq) * D + dl * 8);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[gq][j] = bf2f(e[j]);
+  }
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int gq = 0; gq < G; ++gq) {
+    m[gq] = -1e30f;
+    l[gq] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[gq][j] = 0.f;
+  }
+
+  const int n_tok = pos + 1;
+  for (int t0 = wave * TPW; t0 < n_tok; t0 += NP) {
+    const int t = t0 + sub;
+    const bool valid = t < n_tok;
+    const int tc = valid ? t : pos;
+    const int page = bt[tc / KV_PAGE];
+    const int64_t base = (((int64_t)page * a.KVH + kvh) * KV_PAGE + (tc % KV_PAGE)) * D + dl * 8;
+    uint4 kv = *reinterpret_cast<const uint4*>(a.kpool + base);
+    uint4 vv = *reinterpret_cast<const uint4*>(a.vpool + base);
+    const bf16_t* ke = reinterpret_cast<const bf16_t*>(&kv);
+    const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+    float kf[8], vf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      kf[j] = bf2f(ke[j]);
+      vf[j] = bf2f(ve[j]);
+    }
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += q[gq][j] * kf[j];
+#pragma unroll
+      for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      if (valid) {
+        const float sc = d * scale;
+        const float mn = fmaxf(m[gq], sc);
+        const float corr = __expf(m[gq] - mn);
+        const float p = __expf(sc - mn);
+        l[gq] = l[gq] * corr + p;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[gq][j] = acc[gq][j] * corr + p * vf[j];
+        m[gq] = mn;
+      }
+    }
+  }
+
+  const int pidx = wave * TPW + sub;
+#pragma unroll
+  for (int gq = 0; gq < G; ++gq) {
+    if (dl == 0) {
+      s_m[pidx][gq] = m[gq];
+      s_l[pidx][gq] = l[gq];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_acc[pidx][gq][dl * 8 + j] = acc[gq][j];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < G * D; o += 256) {
+    const int gq = o / D, d = o % D;
+    float M = -1e30f;
+    for (int p = 0; p < NP; ++p) M = fmaxf(M, s_m[p][gq]);
+    float L = 0.f, O = 0.f;
+    for (int p = 0; p < NP; ++p) {
+      const float w = __expf(s_m[p][gq] - M);
+      L += s_l[p][gq] * w;
+      O += s_acc[p][gq][d] * w;
+    }
+    a.out[((int64_t)r * a.H + kvh * G + gq) * D + d] = f2bf(O / L);
+  }
+}
+
+template <int D>
+static int launch_attn_d(const AttnArgs& a, hipStream_t s) {
+  const int G = a.H / a.KVH;
+  dim3 grid(a.rows, a.KVH), block(256);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((attn_kernel<D, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_kernel<D, 2>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((attn_kernel<D, 4>), grid, block, 0, s, a); break;
+    default: return set_error(FMI_EINVAL, "attn: GQA ratio %d unsupported", G);
+  }
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.H % a.KVH == 0, "attn: n_head %% n_local_heads");
+  switch (a.D) {
+    case 32: return launch_attn_d<32>(a, s);
+    case 64: return launch_attn_d<64>(a, s);
+    case 128: return launch_attn_d<128>(a, s);
+    default: return set_error(FMI_EINVAL, "attn: head_dim %d unsupported (32/64/128)", a.D);
+  }
+}
+
+// fast-AR attention (llama.py:948-976), S <= num_codebooks, everything rounded through bf16 like
+// the reference's explicit matmul/softmax chain.  grid (B, KVH), 4 waves.
+__global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
+  __shared__ float s_k[128], s_v[128];
+  const int b = blockIdx.x, kvh = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int D = a.D, H = a.H, KVH = a.KVH, G = H / KVH;
+  const int slot = a.row_slot ? a.row_slot[b] : b;
+  const int pos = a.pos;
+  const bf16_t* src = a.qkv + (int64_t)b * (H + 2 * KVH) * D;
+  bf16_t* kc = a.kc + (((int64_t)slot * KVH + kvh) * a.ncb) * D;
+  bf16_t* vc = a.vc + (((int64_t)slot * KVH + kvh) * a.ncb) * D;
+  const bool act = lane < D / 2;
+  const int p = act ? lane : 0;
+  uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+  const float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
+
+  if (wave == 0) {  // key head: norm + rope -> cache + LDS
+    uint32_t raw = *reinterpret_cast<const uint32_t*>(src + (H + kvh) * D + 2 * p);
+    float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
+    float y0 = x0, y1 = x1;
+    if (a.knw) {
+      float ss = wave_sum(x0 * x0 + x1 * x1);
+      float rstd = rsqrtf(ss / (float)D + a.eps);
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.knw[2 * p])));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.knw[2 * p + 1])));
+    }
+    bf16_t o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
+    bf16_t o1 = f2bf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
+    if (act) {
+      *reinterpret_cast<uint32_t*>(kc + (int64_t)pos * D + 2 * p) = (uint32_t)o0 | ((uint32_t)o1 << 16);
+      s_k[2 * p] = bf2f(o0);
+      s_k[2 * p + 1] = bf2f(o1);
+    }
+  } else if (wave == 1) {  // value head
+    if (act) {
+      uint32_t raw = *reinterpret_cast<const uint32_t*>(src + (H + KVH + kvh) * D + 2 * p);
+      *reinterpret_cast<uint32_t*>(vc + (int64_t)pos * D + 2 * p) = raw;
+      s_v[2 * p] = bf2f((bf16_t)(raw & 0xffff));
+      s_v[2 * p + 1] = bf2f((bf16_t)(raw >> 16));
+    }
+  }
+  __syncthreads();
+
+  const float scale = (float)(1.0 / sqrt((double)D));
+  for (int gq = wave; gq < G; gq += 4) {
+    const int h = kvh * G + gq;
+    uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+    float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
+    float y0 = x0, y1 = x1;
+    if (a.qnw) {
+      float ss = wave_sum(x0 * x0 + x1 * x1);
+      float rstd = rsqrtf(ss / (float)D + a.eps);
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.qnw[2 * p])));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.qnw[2 * p + 1])));
+    }
+    const float q0 = rbf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
+    const float q1 = rbf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
+    float sc[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      sc[t] = 0.f;
+      if (t <= pos) {
+        float k0, k1;
+        if (t == pos) {
+          k0 = s_k[2 * p];
+          k1 = s_k[2 * p + 1];
+        } else {
+          uint32_t kr = *reinterpret_cast<const uint32_t*>(kc + (int64_t)t * D + 2 * p);
+          k0 = bf2f((bf16_t)(kr & 0xffff));
+          k1 = bf2f((bf16_t)(kr >> 16));
+        }
+        float d = act ? (q0 * k0 + q1 * k1) : 0.f;
+        d = wave_sum(d);
+        // query @ key^T -> bf16, * scale -> bf16 (llama.py:971)
+        sc[t] = rbf(rbf(d) * scale);
+        mx = fmaxf(mx, sc[t]);
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t <= pos) {
+        sc[t] = expf(sc[t] - mx);
+        sum += sc[t];
+      }
+    float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t <= pos) {
+        const float pr = rbf(sc[t] / sum);  // softmax output rounded to bf16
+        float v0, v1;
+        if (t == pos) {
+          v0 = s_v[2 * p];
+          v1 = s_v[2 * p + 1];
+        } else {
+          uint32_t vr = *reinterpret_cast<const uint32_t*>(vc + (int64_t)t * D + 2 * p);
+          v0 = bf2f((bf16_t)(vr & 0xffff));
+          v1 = bf2f((bf16_t)(vr >> 16));
+        }
+        o0 += pr * v0;
+        o1 += pr * v1;
+      }
+    if (act)
+      *reinterpret_cast<uint32_t*>(a.out + ((int64_t)b * H + h) * D + 2 * p) =
+          (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+  }
+}
+
+int launch_fast_attn(const FastAttnArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.D <= 128 && a.D % 2 == 0 && a.ncb <= 16 && a.pos < a.ncb, "fast_attn: unsupported shape");
+  hipLaunchKernelGGL(fast_attn_kernel, dim3(a.B, a.KVH), dim3(256), 0, s, a);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// =====================================================================================
+// sampler (inference.py:43-93, 118-144)
+// =====================================================================================
+
+__device__ inline uint32_t fmi_rand_u8(uint32_t seed, uint32_t stream, uint32_t frame, uint32_t draw, uint32_t i) {
+  uint32_t x = seed * 0x9E3779B1u + stream * 0x85EBCA77u + frame * 0xC2B2AE3Du + draw * 0x27D4EB2Fu + i * 0x165667B1u;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x >> 24;
+}
+
+__device__ inline uint32_t order_key(bf16_t v) {  // larger key <=> larger value
+  return (v & 0x8000) ? (uint32_t)(~v & 0xffff) : (uint32_t)(v | 0x8000);
+}
+
+struct SamplerShared {
+  uint32_t hist[256];
+  uint32_t scan[256];
+  int sel[4];             // b1, cnt_above, b2, ...
+  float redf[8];
+  int redi[8];
+  int cand_idx[SAMPLER_MAXK];
+  uint32_t cand_key[SAMPLER_MAXK];
+  float s_val[SAMPLER_MAXK];   // sorted logits (fp32 of bf16)
+  int s_idx[SAMPLER_MAXK];     // sorted row indices
+  float s_p[SAMPLER_MAXK];     // softmax probs (bf16 values)
+  float s_cum[SAMPLER_MAXK];   // cumulative (bf16 values)
+  float s_e[SAMPLER_MAXK];
+};
+
+// suffix counts: scan[b] = sum_{j>=b} hist[j]  (256 threads)
+__device__ inline void suffix_scan(SamplerShared& sh, int tid) {
+  sh.scan[tid] = sh.hist[tid];
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    uint32_t v = (tid + o < 256) ? sh.scan[tid + o] : 0;
+    __syncthreads();
+    sh.scan[tid] += v;
+    __syncthreads();
+  }
+}
+
+__device__ inline float block_sum(SamplerShared& sh, float v, int tid) {
+  v = wave_sum(v);
+  if ((tid & 63) == 0) sh.redf[tid >> 6] = v;
+  __syncthreads();
+  float r = sh.redf[0] + sh.redf[1] + sh.redf[2] + sh.redf[3];
+  __syncthreads();
+  return r;
+}
+
+// One constrained draw from the prepared candidate list.  Returns the ROW index (or -1 when every
+// value is 0 -- the reference's argmax then lands on vocabulary index 0).
+__device__ int sampler_draw(SamplerShared& sh, int k, float temperature, float top_p, uint32_t seed, uint32_t stream,
+                            uint32_t frame, uint32_t draw, const int32_t* ids, int tid) {
+  const float tc = rbf(fmaxf(temperature, rbf(1e-5f)));
+  // kept_r = r==0 || !(cum_r > top_p); tempered logits; exp against the rank-0 value
+  float esum = 0.f;
+  const float l0 = rbf(sh.s_val[0] / tc);
+  for (int r = tid; r < k; r += 256) {
+    const bool keep = (r == 0) || !(sh.s_cum[r] > top_p);
+    float e = 0.f;
+    if (keep) e = expf(rbf(sh.s_val[r] / tc) - l0);
+    sh.s_e[r] = e;
+    esum += e;
+  }
+  esum = block_sum(sh, esum, tid);
+  float best = -1.f;
+  int best_id = 0x7fffffff, best_row = -1;
+  for (int r = tid; r < k; r += 256) {
+    const float e = sh.s_e[r];
+    if (e > 0.f) {
+      const float pr = rbf(e / esum);
+      const int row = sh.s_idx[r];
+      const int vid = ids ? ids[row] : row;
+      const uint32_t u8 = fmi_rand_u8(seed, stream, frame, draw, (uint32_t)vid);
+      const float qv = -rbf(logf((float)u8 * (1.0f / 256.0f)));  // -log(u) in bf16; u=0 -> +inf
+      const float val = rbf(pr / qv);
+      if (val > best || (val == best && vid < best_id)) {
+        best = val;
+        best_id = vid;
+        best_row = row;
+      }
+    }
+  }
+  // block arg-max with lowest-vocab-id tie break
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(best_id, o, 64);
+    int orow = __shfl_xor(best_row, o, 64);
+    if (ov > best || (ov == best && oi < best_id)) {
+      best = ov;
+      best_id = oi;
+      best_row = orow;
+    }
+  }
+  __shared__ float wb[4];
+  __shared__ int wi[4], wr[4];
+  if ((tid & 63) == 0) {
+    wb[tid >> 6] = best;
+    wi[tid >> 6] = best_id;
+    wr[tid >> 6] = best_row;
+  }
+  __syncthreads();
+  best = wb[0];
+  best_id = wi[0];
+  best_row = wr[0];
+  for (int w = 1; w < 4; ++w)
+    if (wb[w] > best || (wb[w] == best && wi[w] < best_id)) {
+      best = wb[w];
+      best_id = wi[w];
+      best_row = wr[w];
+    }
+  __syncthreads();
+  if (!(best > 0.f)) return -1;
+  return best_row;
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  SamplerShared& sh = *reinterpret_cast<SamplerShared*>(smem_raw);
+  uint16_t* skey = reinterpret_cast<uint16_t*>(smem_raw + sizeof(SamplerShared));
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int slot = a.row_slot ? a.row_slot[b] : b;
+  const bf16_t* lg = a.logits + (int64_t)b * a.ld;
+  const int n = a.n;
+
+  float temperature, top_p;
+  int top_k;
+  uint32_t seed;
+  int frame, draw0, use_ras;
+  if (a.mode == 2) {
+    temperature = a.temperature; top_p = a.top_p; top_k = a.top_k; seed = a.seed;
+    frame = a.frame; draw0 = a.draw; use_ras = a.prev != nullptr;
+  } else {
+    temperature = a.st.temperature[slot]; top_p = a.st.top_p[slot]; top_k = a.st.top_k[slot];
+    seed = a.st.seed[slot]; frame = a.st.frame[slot];
+    draw0 = (a.mode == 0) ? 0 : 1 + a.cb;
+    use_ras = a.st.use_ras[slot] && frame > 0;
+  }
+  int k = top_k < n ? top_k : n;
+  if (k > SAMPLER_MAXK) k = SAMPLER_MAXK;
+  if (k < 1) k = 1;
+
+  // --- pass 1: keys, max, high-byte histogram
+  sh.hist[tid] = 0;
+  __syncthreads();
+  const int ept = (n + 255) / 256;
+  const int i0 = tid * ept, i1 = min(n, i0 + ept);
+  uint32_t kmax = 0;
+  for (int i = i0; i < i1; ++i) {
+    uint32_t key = order_key(lg[i]);
+    skey[i] = (uint16_t)key;
+    kmax = max(kmax, key);
+    atomicAdd(&sh.hist[key >> 8], 1u);
+  }
+  for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+  if ((tid & 63) == 0) sh.redi[tid >> 6] = (int)kmax;
+  __syncthreads();
+  kmax = (uint32_t)max(max(sh.redi[0], sh.redi[1]), max(sh.redi[2], sh.redi[3]));
+  const bf16_t maxbits = (kmax & 0x8000) ? (bf16_t)(kmax & 0x7fff) : (bf16_t)(~kmax & 0xffff);
+  const float vmax = bf2f(maxbits);
+
+  // --- softmax denominator over ALL entries (softmax of the un-tempered sorted logits)
+  float se = 0.f;
+  for (int i = tid; i < n; i += 256) se += expf(bf2f(lg[i]) - vmax);
+  const float sumexp = block_sum(sh, se, tid);
+
+  // --- radix select of the k-th largest key (two 8-bit levels)
+  suffix_scan(sh, tid);
+  {
+    const uint32_t here = sh.scan[tid], above = (tid < 255) ? sh.scan[tid + 1] : 0;
+    if (here >= (uint32_t)k && above < (uint32_t)k) {
+      sh.sel[0] = tid;
+      sh.sel[1] = (int)above;
+    }
+  }
+  __syncthreads();
+  const int b1 = sh.sel[0];
+  const int above1 = sh.sel[1];
+  sh.hist[tid] = 0;
+  __syncthreads();
+  for (int i = i0; i < i1; ++i) {
+    uint32_t key = skey[i];
+    if ((int)(key >> 8) == b1) atomicAdd(&sh.hist[key & 255], 1u);
+  }
+  __syncthreads();
+  suffix_scan(sh, tid);
+  {
+    const uint32_t k2 = (uint32_t)(k - above1);
+    const uint32_t here = sh.scan[tid], above = (tid < 255) ? sh.scan[tid + 1] : 0;
+    if (here >= k2 && above < k2) {
+      sh.sel[2] = tid;
+      sh.sel[3] = (int)above;
+    }
+  }
+  __syncthreads();
+  const uint32_t thr = ((uint32_t)b1 << 8) | (uint32_t)sh.sel[2];
+  const int c_gt = above1 + sh.sel[3];
+  const int need_eq = k - c_gt;
+
+  // --- collect candidates in index order: keys > thr, then the first need_eq keys == thr
+  int my_gt = 0, my_eq = 0;
+  for (int i = i0; i < i1; ++i) {
+    uint32_t key = skey[i];
+    my_gt += key > thr;
+    my_eq += key == thr;
+  }
+  sh.hist[tid] = (uint32_t)my_gt;
+  sh.scan[tid] = (uint32_t)my_eq;
+  __syncthreads();
+  // exclusive prefix sums over threads (thread chunks are contiguous index ranges)
+  int off_gt = 0, off_eq = 0;
+  for (int t = 0; t < tid; ++t) {
+    off_gt += (int)sh.hist[t];
+    off_eq += (int)sh.scan[t];
+  }
+  for (int i = i0; i < i1; ++i) {
+    uint32_t key = skey[i];
+    if (key > thr) {
+      sh.cand_idx[off_gt] = i;
+      sh.cand_key[off_gt] = key;
+      ++off_gt;
+    } else if (key == thr) {
+      if (off_eq < need_eq) {
+        sh.cand_idx[c_gt + off_eq] = i;
+        sh.cand_key[c_gt + off_eq] = key;
+      }
+      ++off_eq;
+    }
+  }
+  __syncthreads();
+  // --- rank sort: (key desc, index asc); ties among equal logits -> ascending index
+  for (int c = tid; c < k; c += 256) {
+    const uint32_t kc = sh.cand_key[c];
+    const int ic = sh.cand_idx[c];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const uint32_t kj = sh.cand_key[j];
+      rank += (kj > kc) || (kj == kc && sh.cand_idx[j] < ic);
+    }
+    const bf16_t bits = (kc & 0x8000) ? (bf16_t)(kc & 0x7fff) : (bf16_t)(~kc & 0xffff);
+    const float v = bf2f(bits);
+    sh.s_val[rank] = v;
+    sh.s_idx[rank] = ic;
+    sh.s_p[rank] = rbf(expf(v - vmax) / sumexp);
+  }
+  __syncthreads();
+  if (tid == 0) {  // torch.cumsum on bf16: fp32 running sum, each output rounded to bf16
+    float c = 0.f;
+    for (int r = 0; r < k; ++r) {
+      c += sh.s_p[r];
+      sh.s_cum[r] = rbf(c);
+    }
+  }
+  __syncthreads();
+
+  const int32_t* ids = a.ids;
+  int row = sampler_draw(sh, k, temperature, top_p, seed, (uint32_t)slot, (uint32_t)frame, (uint32_t)draw0, ids, tid);
+  int tok = (row < 0) ? 0 : (ids ? ids[row] : row);
+
+  if (a.mode == 1) {  // fast codebook draw
+    if (tid == 0) a.st.cur[(int64_t)slot * a.st.ncb1 + 1 + a.cb] = tok;
+  } else {
+    // second draw at RAS_HIGH_TEMP / RAS_HIGH_TOP_P (inference.py:126-131); always consumed
+    const bool second = (a.mode == 0) || (a.prev != nullptr);
+    if (second) {
+      int row_h = sampler_draw(sh, k, 1.0f, rbf(0.9f), seed, (uint32_t)slot, (uint32_t)frame, (uint32_t)draw0 + 1, ids, tid);
+      int tok_h = (row_h < 0) ? 0 : (ids ? ids[row_h] : row_h);
+      if (use_ras) {
+        const int32_t* win = (a.mode == 2) ? a.prev + (int64_t)b * RAS_WIN
+                                           : a.st.window + (int64_t)slot * a.st.ncb1 * RAS_WIN;
+        bool inwin = false;
+        for (int j = 0; j < RAS_WIN; ++j) inwin |= (win[j] == tok);
+        const bool sem = tok >= a.sem_begin && tok <= a.sem_end;
+        if (inwin && sem) tok = tok_h;
+      }
+    }
+    if (a.mode == 2) {
+      if (tid == 0) a.out_tok[b] = tok;
+      return;
+    }
+    int cb0 = tok - a.sem_begin;
+    cb0 = cb0 < 0 ? 0 : (cb0 > a.cbs - 1 ? a.cbs - 1 : cb0);
+    if (tid == 0) {
+      a.st.cur[(int64_t)slot * a.st.ncb1 + 0] = tok;
+      a.st.cur[(int64_t)slot * a.st.ncb1 + 1] = cb0;
+    }
+    tok = cb0;
+  }
+  // gather fast_embeddings[code] as the next fast step's input (inference.py:157,172)
+  if (a.xf) {
+    const bf16_t* src = a.fast_emb + (int64_t)tok * a.fdim;
+    for (int c = tid * 8; c < a.fdim; c += 256 * 8)
+      *reinterpret_cast<uint4*>(a.xf + (int64_t)b * a.fdim + c) = *reinterpret_cast<const uint4*>(src + c);
+  }
+  // frame bookkeeping after the last codebook (decode_n_tokens, inference.py:224-233)
+  if (a.mode == 1 && a.cb == a.st.ncb1 - 2) {
+    __syncthreads();
+    if (tid == 0) {
+      const int ncb1 = a.st.ncb1;
+      int32_t* cur = a.st.cur + (int64_t)slot * ncb1;
+      cur[ncb1 - 1] = tok;
+      if (!a.st.done[slot]) {
+        const int f = a.st.frame[slot];
+        if (f < a.st.max_frames) {
+          int32_t* o = a.st.out + ((int64_t)slot * a.st.max_frames + f) * ncb1;
+          for (int j = 0; j < ncb1; ++j) o[j] = cur[j];
+        }
+        if (f > 0) {  // the prefill frame is not inserted into the RAS window
+          int32_t* win = a.st.window + (int64_t)slot * ncb1 * RAS_WIN;
+          for (int j = 0; j < ncb1; ++j) {
+            for (int w = 0; w < RAS_WIN - 1; ++w) win[j * RAS_WIN + w] = win[j * RAS_WIN + w + 1];
+            win[j * RAS_WIN + RAS_WIN - 1] = cur[j];
+          }
+        }
+        a.st.frame[slot] = f + 1;
+        // the prefill step leaves pos at T (set by the host); decode steps advance by one
+        if (f > 0) a.st.pos[slot] += 1;
+        if (cur[0] == a.im_end) a.st.done[slot] = 1;
+        else if (a.st.pos[slot] >= a.st.limit[slot] || f + 1 >= a.st.max_frames) a.st.done[slot] = 2;
+      }
+    }
+  }
+}
+
+int launch_sample(const SampleArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.n >= 1 && a.n <= 65536, "sample: n=%d out of range", a.n);
+  size_t smem = sizeof(SamplerShared) + (size_t)a.n * 2 + 16;
+  hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), smem, s, a);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+}  // namespace fmi

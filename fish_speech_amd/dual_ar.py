@@ -1,0 +1,483 @@
+"""Host-side mirror of the reference's Dual-AR seams, driving libfishmi.so through ctypes.
+
+Reference surface mirrored (fish_speech/models/text2semantic/):
+  * ``DualARTransformer`` as used by inference.py (llama.py:660-828): ``config``, ``tokenizer``,
+    ``parameters()``, ``setup_caches``, ``eval``, ``to``           -> :class:`MiDualAR`
+  * ``decode_one_token_ar`` (inference.py:96-181), the callable every caller threads through
+    ``generate``/``generate_long``                                  -> :func:`decode_one_token`
+  * ``generate`` (inference.py:243-359)                             -> :func:`generate`
+  * new capability (the reference is batch-1 only): :func:`generate_batch`.
+
+PyTorch here is plumbing only: device buffers, streams, checkpoint reading.  Every FLOP of the
+path runs in the HIP kernels of ``csrc/``; there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+import json
+import math
+import os
+from dataclasses import dataclass, fields
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import DualARConfigC, SamplingC, check
+
+IM_END_TOKEN = "<|im_end|>"  # fish_speech/tokenizer.py
+
+
+@dataclass
+class DualARConfig:
+    """Fields of DualARModelArgs (llama.py:27-193) that the inference path reads."""
+
+    vocab_size: int
+    n_layer: int
+    n_head: int
+    n_local_heads: int
+    head_dim: int
+    dim: int
+    intermediate_size: int
+    codebook_size: int
+    num_codebooks: int
+    semantic_begin_id: int
+    semantic_end_id: int
+    im_end_id: int
+    max_seq_len: int = 2048
+    rope_base: float = 10000.0
+    norm_eps: float = 1e-5
+    attention_qk_norm: bool = False
+    scale_codebook_embeddings: bool = False
+    norm_fastlayer_input: bool = False
+    n_fast_layer: int = 4
+    fast_dim: Optional[int] = None
+    fast_n_head: Optional[int] = None
+    fast_n_local_heads: Optional[int] = None
+    fast_head_dim: Optional[int] = None
+    fast_intermediate_size: Optional[int] = None
+    fast_attention_qk_norm: Optional[bool] = None
+
+    def __post_init__(self):  # defaults follow llama.py:165-193
+        self.fast_dim = self.fast_dim or self.dim
+        self.fast_n_head = self.fast_n_head or self.n_head
+        self.fast_n_local_heads = self.fast_n_local_heads or self.n_local_heads
+        self.fast_head_dim = self.fast_head_dim or self.head_dim
+        self.fast_intermediate_size = self.fast_intermediate_size or self.intermediate_size
+        if self.fast_attention_qk_norm is None:
+            self.fast_attention_qk_norm = self.attention_qk_norm
+
+    @classmethod
+    def from_any(cls, cfg, im_end_id: Optional[int] = None) -> "DualARConfig":
+        """Accept the reference's DualARModelArgs, the oracle's config, or a dict."""
+        get = (lambda k, d=None: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d=None: getattr(cfg, k, d))
+        kw = {}
+        for f in fields(cls):
+            v = get(f.name)
+            if v is not None:
+                kw[f.name] = v
+        if im_end_id is not None:
+            kw["im_end_id"] = im_end_id
+        if "im_end_id" not in kw:
+            raise ValueError("im_end_id is required (tokenizer.get_token_id('<|im_end|>'))")
+        return cls(**kw)
+
+    @classmethod
+    def from_fish_qwen3_omni(cls, data: dict, im_end_id: int, semantic_begin_id: Optional[int] = None,
+                             semantic_end_id: Optional[int] = None) -> "DualARConfig":
+        """config.json of model_type 'fish_qwen3_omni' (llama.py:90-143)."""
+        tc, adc = data["text_config"], data["audio_decoder_config"]
+        return cls(
+            vocab_size=tc["vocab_size"], n_layer=tc["n_layer"], n_head=tc["n_head"],
+            n_local_heads=tc.get("n_local_heads", -1) if tc.get("n_local_heads", -1) != -1 else tc["n_head"],
+            head_dim=tc.get("head_dim") or tc["dim"] // tc["n_head"], dim=tc["dim"],
+            intermediate_size=tc["intermediate_size"], rope_base=tc.get("rope_base", 10000),
+            norm_eps=tc.get("norm_eps", 1e-5), max_seq_len=tc.get("max_seq_len", 2048),
+            attention_qk_norm=tc.get("attention_qk_norm", False),
+            semantic_begin_id=semantic_begin_id if semantic_begin_id is not None else data.get("semantic_start_token_id", 0),
+            semantic_end_id=semantic_end_id if semantic_end_id is not None else data.get("semantic_end_token_id", 0),
+            im_end_id=im_end_id, scale_codebook_embeddings=True, norm_fastlayer_input=True,
+            codebook_size=adc["vocab_size"], num_codebooks=adc["num_codebooks"], n_fast_layer=adc["n_layer"],
+            fast_dim=adc.get("dim"), fast_n_head=adc.get("n_head"), fast_n_local_heads=adc.get("n_local_heads"),
+            fast_head_dim=adc.get("head_dim"), fast_intermediate_size=adc.get("intermediate_size"),
+            fast_attention_qk_norm=adc.get("attention_qk_norm"),
+        )
+
+    def to_c(self) -> DualARConfigC:
+        c = DualARConfigC()
+        for name, _ in DualARConfigC._fields_:
+            v = getattr(self, name)
+            setattr(c, name, float(v) if name in ("rope_base", "norm_eps") else int(v))
+        return c
+
+
+def remap_fish_qwen3_omni_keys(weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """HF checkpoint names -> model names (same mapping as llama.py:229-246)."""
+    if not any(k.startswith(("text_model.", "audio_decoder.")) for k in weights):
+        return weights
+    out = {}
+    for k, v in weights.items():
+        if k.startswith("text_model.model."):
+            out[k[len("text_model.model."):]] = v
+        elif k.startswith("audio_decoder."):
+            s = k[len("audio_decoder."):]
+            out[s if s.startswith("codebook_embeddings.") else "fast_" + s] = v
+        else:
+            out[k] = v
+    return out
+
+
+def _rope_table(seq_len: int, n_elem: int, base: float) -> torch.Tensor:
+    """llama.py:1004-1023, built with torch on the host so the bf16 table is the reference's."""
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
+    f = torch.outer(torch.arange(seq_len), freqs)
+    cis = torch.polar(torch.ones_like(f), f)
+    return torch.stack([cis.real, cis.imag], dim=-1).to(torch.bfloat16).reshape(seq_len, n_elem).contiguous()
+
+
+class _FakeTokenizer:
+    def __init__(self, im_end_id):
+        self.im_end_id = im_end_id
+
+    def get_token_id(self, token):
+        if token != IM_END_TOKEN:
+            raise KeyError(token)
+        return self.im_end_id
+
+
+@dataclass
+class ForwardResult:
+    logits: torch.Tensor
+    hidden_states: torch.Tensor
+
+
+class MiDualAR:
+    """DualARTransformer-shaped object whose compute lives in libfishmi.so."""
+
+    def __init__(self, config, device="cuda:0", im_end_id: Optional[int] = None, tokenizer=None):
+        self.lib = _lib.load()
+        if tokenizer is not None and im_end_id is None:
+            im_end_id = tokenizer.get_token_id(IM_END_TOKEN)
+        self.config = config if isinstance(config, DualARConfig) else DualARConfig.from_any(config, im_end_id)
+        self.tokenizer = tokenizer if tokenizer is not None else _FakeTokenizer(self.config.im_end_id)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.FishmiError("MiDualAR needs a GPU device (no CPU fallback)")
+        torch.cuda.set_device(self.device)
+        self._c = self.config.to_c()
+        need = self.lib.fmi_dualar_arena_bytes(C.byref(self._c))
+        if need < 0:
+            check(-1)
+        # one contiguous blob: a single RCCL broadcast replicates the weights (dist.py)
+        self.arena = torch.empty(need, dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        check(self.lib.fmi_dualar_create(C.byref(self._c), C.c_void_p(self.arena.data_ptr()), need, C.byref(h)))
+        self._h = h
+        self._cache_setup_done = False
+        self.max_batch_size = -1
+        self.max_seq_len = -1
+        self._frame_index = 0
+        self._seed_counter = itertools.count()
+        self._dtype_probe = torch.empty(0, dtype=torch.bfloat16, device=self.device)
+        self.fixed_temperature = torch.tensor(0.7, device=self.device)
+        self.fixed_top_p = torch.tensor(0.7, device=self.device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.fmi_dualar_destroy(h)
+            self._h = None
+
+    # ---- nn.Module-ish surface used by inference.py (277-279, 557, 377, 392)
+    def parameters(self) -> Iterable[torch.Tensor]:
+        yield self._dtype_probe
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- weights
+    def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True):
+        """Row-major bf16 tensors by reference key; re-tiled inside the library."""
+        state = remap_fish_qwen3_omni_keys(dict(state))
+        # separate wq/wk/wv -> wqkv (Attention.load_hook, llama.py:877-882)
+        for k in [k for k in state if k.endswith("attention.wq.weight")]:
+            pre = k[: -len("wq.weight")]
+            state[pre + "wqkv.weight"] = torch.cat([state.pop(pre + "wq.weight"), state.pop(pre + "wk.weight"),
+                                                    state.pop(pre + "wv.weight")])
+        cfg = self.config
+        state.setdefault("freqs_cis", _rope_table(cfg.max_seq_len, cfg.head_dim, cfg.rope_base))
+        state.setdefault("fast_freqs_cis", _rope_table(cfg.num_codebooks, cfg.fast_head_dim, cfg.rope_base))
+        s = self._stream()
+        for name, t in state.items():
+            if name in ("causal_mask",):
+                continue
+            t = t.detach()
+            if t.dtype != torch.bfloat16:
+                t = t.to(torch.bfloat16)
+            t = t.to(self.device).contiguous()
+            rows, cols = (1, t.numel()) if t.dim() == 1 else (t.shape[0], t.numel() // t.shape[0])
+            rc = self.lib.fmi_dualar_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), rows, cols, 1, s)
+            if rc != 0 and not strict:
+                continue
+            check(rc)
+            torch.cuda.current_stream(self.device).synchronize()
+        check(self.lib.fmi_dualar_finalize_weights(self._h, s))
+        torch.cuda.current_stream(self.device).synchronize()
+        return self
+
+    def weights_ready(self):
+        """After a broadcast filled the arena on a non-loading rank."""
+        check(self.lib.fmi_dualar_weights_ready(self._h))
+
+    @classmethod
+    def from_state_dict(cls, config, state, device="cuda:0", im_end_id=None) -> "MiDualAR":
+        return cls(config, device=device, im_end_id=im_end_id).load_state_dict(state)
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda:0", max_length: Optional[int] = None) -> "MiDualAR":
+        """Checkpoint directory loader (llama.py:480-594): config.json + safetensors / model.pth."""
+        from safetensors.torch import load_file
+
+        with open(os.path.join(path, "config.json")) as f:
+            data = json.load(f)
+        tokenizer = None
+        try:  # the reference injects the semantic id range from its tokenizer (llama.py:499-510)
+            from fish_speech.tokenizer import FishTokenizer  # type: ignore
+
+            tokenizer = FishTokenizer.from_pretrained(path)
+        except Exception:
+            tokenizer = None
+        if tokenizer is None:
+            raise _lib.FishmiError("from_pretrained needs fish_speech.tokenizer.FishTokenizer for the id ranges")
+        im_end = tokenizer.get_token_id(IM_END_TOKEN)
+        if data.get("model_type") == "fish_qwen3_omni":
+            cfg = DualARConfig.from_fish_qwen3_omni(data, im_end, tokenizer.semantic_begin_id,
+                                                    tokenizer.semantic_end_id)
+        else:
+            data = dict(data, semantic_begin_id=tokenizer.semantic_begin_id,
+                        semantic_end_id=tokenizer.semantic_end_id)
+            cfg = DualARConfig.from_any(data, im_end)
+        if max_length is not None:
+            cfg.max_seq_len = max_length
+        model = cls(cfg, device=device, tokenizer=tokenizer)
+        index = os.path.join(path, "model.safetensors.index.json")
+        weights: Dict[str, torch.Tensor] = {}
+        if os.path.exists(index):
+            with open(index) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+            for sh in shards:
+                weights.update(load_file(os.path.join(path, sh), device="cpu"))
+        elif os.path.exists(os.path.join(path, "model.safetensors")):
+            weights = load_file(os.path.join(path, "model.safetensors"), device="cpu")
+        elif os.path.exists(os.path.join(path, "model.pth")):
+            weights = torch.load(os.path.join(path, "model.pth"), map_location="cpu", mmap=True, weights_only=True)
+            weights = weights.get("state_dict", weights)
+            if weights and next(iter(weights)).startswith("model."):
+                weights = {k.replace("model.", ""): v for k, v in weights.items()}
+            weights = {k: v for k, v in weights.items() if "audio_" not in k}
+        else:
+            raise FileNotFoundError(f"No model weights found in {path}")
+        return model.load_state_dict(weights, strict=False)
+
+    # ---- caches (llama.py:307-324,708-722)
+    def setup_caches(self, max_batch_size: int, max_seq_len: int, dtype: torch.dtype = torch.bfloat16):
+        if dtype != torch.bfloat16:
+            raise _lib.FishmiError("only bfloat16 KV caches are implemented")
+        if self.max_seq_len >= max_seq_len and self.max_batch_size >= max_batch_size:
+            return
+        check(self.lib.fmi_dualar_setup_caches(self._h, int(max_batch_size), int(max_seq_len)))
+        self.max_batch_size, self.max_seq_len = max_batch_size, max_seq_len
+        self._cache_setup_done = True
+
+    # ---- batched API (new capability)
+    def _sampling(self, temperature, top_p, top_k, seed, use_ras=True) -> SamplingC:
+        return SamplingC(float(temperature), float(top_p), int(top_k), int(seed) & 0xFFFFFFFF, int(bool(use_ras)))
+
+    def next_seed(self) -> int:
+        return (torch.initial_seed() + 0x9E37 * next(self._seed_counter)) & 0xFFFFFFFF
+
+    def prefill(self, slots: Sequence[int], prompts: Sequence[torch.Tensor], max_new_tokens: Sequence[int],
+                sampling: Sequence[SamplingC]):
+        """prompts[i]: (1+ncb, T_i) integer tensor (the reference's prompt layout)."""
+        n = len(slots)
+        toks = torch.cat([p.to(self.device).t().to(torch.int32) for p in prompts], dim=0).contiguous()
+        lens = (C.c_int32 * n)(*[int(p.shape[1]) for p in prompts])
+        sl = (C.c_int32 * n)(*[int(s) for s in slots])
+        mn = (C.c_int32 * n)(*[int(m) for m in max_new_tokens])
+        sp = (SamplingC * n)(*sampling)
+        check(self.lib.fmi_dualar_prefill(self._h, n, sl, C.c_void_p(toks.data_ptr()), lens, mn, sp, self._stream()))
+        self._keep = toks
+
+    def decode(self, slots: Sequence[int], n_frames: int):
+        n = len(slots)
+        sl = (C.c_int32 * n)(*[int(s) for s in slots])
+        check(self.lib.fmi_dualar_decode(self._h, n, sl, int(n_frames), self._stream()))
+
+    def poll_done(self, slots: Sequence[int]) -> List[int]:
+        n = len(slots)
+        sl = (C.c_int32 * n)(*[int(s) for s in slots])
+        out = (C.c_int32 * n)()
+        check(self.lib.fmi_dualar_poll_done(self._h, n, sl, out, self._stream()))
+        return list(out)
+
+    def read(self, slot: int):
+        """-> (frames (n, 1+ncb) int32 CPU tensor, done flag)."""
+        cap = self.max_seq_len
+        ncb1 = self.config.num_codebooks + 1
+        buf = (C.c_int32 * (cap * ncb1))()
+        n, done = C.c_int(), C.c_int()
+        check(self.lib.fmi_dualar_read(self._h, int(slot), buf, cap, C.byref(n), C.byref(done), self._stream()))
+        t = torch.frombuffer(buf, dtype=torch.int32)[: n.value * ncb1].reshape(n.value, ncb1).clone()
+        return t, done.value
+
+    def release(self, slot: int):
+        check(self.lib.fmi_dualar_release(self._h, int(slot)))
+
+    def last_decode_stats(self):
+        ms, nl = C.c_float(), C.c_int()
+        check(self.lib.fmi_dualar_last_decode_stats(self._h, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    def set_graph(self, enable: bool):
+        check(self.lib.fmi_dualar_set_graph(self._h, int(enable)))
+
+    def set_ignore_eos(self, enable: bool):
+        """Keep generating past <|im_end|> (fixed-length synthetic benchmarks)."""
+        check(self.lib.fmi_dualar_set_ignore_eos(self._h, int(enable)))
+
+    # ---- parity taps
+    def debug_taps(self, B: int = 1):
+        """(slow live-row logits (B, n_live) bf16, live vocab ids, normed hidden (B, dim), last fast logits)."""
+        p_log, p_ids, p_hid, p_fl = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n_live, ld = C.c_int(), C.c_int()
+        check(self.lib.fmi_dualar_debug_ptrs(self._h, C.byref(p_log), C.byref(n_live), C.byref(ld), C.byref(p_ids),
+                                             C.byref(p_hid), C.byref(p_fl)))
+        torch.cuda.synchronize(self.device)
+        cfg = self.config
+        logits = _from_ptr(p_log.value, (B, ld.value), torch.bfloat16, self.device)[:, : n_live.value].clone()
+        ids = _from_ptr(p_ids.value, (n_live.value,), torch.int32, self.device).clone()
+        hidden = _from_ptr(p_hid.value, (B, cfg.dim), torch.bfloat16, self.device).clone()
+        fl = _from_ptr(p_fl.value, (B, cfg.codebook_size), torch.bfloat16, self.device).clone()
+        return logits, ids, hidden, fl
+
+    def set_trace(self, enable: bool):
+        p = C.c_void_p()
+        check(self.lib.fmi_dualar_set_trace(self._h, int(enable), C.byref(p)))
+        self._trace_ptr = p.value
+
+    def fast_trace(self, B: int = 1) -> torch.Tensor:
+        cfg = self.config
+        torch.cuda.synchronize(self.device)
+        return _from_ptr(self._trace_ptr, (B, cfg.num_codebooks, cfg.codebook_size), torch.bfloat16,
+                         self.device).clone()
+
+    def step(self, x: torch.Tensor, pos0: int, sampling: SamplingC, previous_tokens: Optional[torch.Tensor],
+             frame_index: int, slot: int = 0) -> torch.Tensor:
+        """One frame for one slot = the decode_one_token seam.  x: (S, 1+ncb) int32 on device."""
+        ncb1 = self.config.num_codebooks + 1
+        out = torch.empty(ncb1, dtype=torch.int32, device=self.device)
+        prev = None
+        if previous_tokens is not None:
+            prev = previous_tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        check(self.lib.fmi_dualar_step(self._h, slot, C.c_void_p(x.data_ptr()), int(x.shape[0]), int(pos0),
+                                       C.byref(sampling), C.c_void_p(prev.data_ptr()) if prev is not None else None,
+                                       int(frame_index), C.c_void_p(out.data_ptr()), self._stream()))
+        self._keep = (x, prev)
+        return out
+
+
+class _CudaArray:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": tuple(shape), "typestr": typestr,
+                                         "version": 2, "strides": None}
+
+
+def _from_ptr(ptr: int, shape, dtype, device) -> torch.Tensor:
+    """View library-owned device memory as a tensor (tests / debug only)."""
+    n = int(math.prod(shape))
+    esize = torch.empty(0, dtype=dtype).element_size()
+    raw = torch.as_tensor(_CudaArray(ptr, (n * esize,), "|u1"), device=device)
+    return raw.view(dtype).reshape(shape)
+
+
+# --------------------------------------------------------------------------- reference-shaped callables
+
+
+def decode_one_token(model: MiDualAR, x: torch.Tensor, input_pos: torch.Tensor, temperature, top_p, top_k: int,
+                     semantic_logit_bias=None, audio_masks=None, audio_parts=None,
+                     previous_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Drop-in for decode_one_token_ar (inference.py:96-181): same arguments, same (1+ncb, 1) int
+    result.  ``semantic_logit_bias`` is implied by the config (only semantic ids + <|im_end|> are ever
+    scored: the algorithmic minimum of the reference's -inf bias); audio_* are dead for S2."""
+    ncb1 = model.config.num_codebooks + 1
+    xs = x.reshape(ncb1, -1).t().to(device=model.device, dtype=torch.int32).contiguous()
+    S = xs.shape[0]
+    pos0 = int(input_pos.reshape(-1)[0].item())
+    if S > 1 or previous_tokens is None:
+        model._frame_index = 0
+        model._call_seed = model.next_seed()
+    else:
+        model._frame_index += 1
+    sp = model._sampling(float(temperature), float(top_p), top_k, getattr(model, "_call_seed", 0),
+                         previous_tokens is not None)
+    out = model.step(xs, pos0, sp, previous_tokens, model._frame_index)
+    return out.view(ncb1, 1)
+
+
+@torch.no_grad()
+def generate(*, model: MiDualAR, prompt: torch.Tensor, max_new_tokens: int, audio_masks=None, audio_parts=None,
+             decode_one_token=None, num_samples: int = 1, poll_every: int = 16, seed: Optional[int] = None,
+             stop_on_im_end: bool = True, **sampling_kwargs) -> torch.Tensor:
+    """Drop-in for generate (inference.py:243-359) on one utterance, without the per-frame host sync:
+    frames advance by hipGraph replay and <|im_end|> is polled every ``poll_every`` frames."""
+    return generate_batch(model=model, prompts=[prompt], max_new_tokens=max_new_tokens, poll_every=poll_every,
+                          seeds=None if seed is None else [seed], stop_on_im_end=stop_on_im_end,
+                          **sampling_kwargs)[0]
+
+
+@torch.no_grad()
+def generate_batch(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_tokens: int, poll_every: int = 16,
+                   seeds: Optional[Sequence[int]] = None, stop_on_im_end: bool = True, temperature: float = 1.0,
+                   top_p: float = 0.9, top_k: int = 30, use_ras: bool = True) -> List[torch.Tensor]:
+    """Batch of utterances through prefill + graph-replayed decode.  Each result equals what the
+    batch-1 path yields for that utterance (kernels are batch-invariant).  Returns, per utterance,
+    (1+ncb, T_i + n_i) like the reference's ``generate``."""
+    cfg = model.config
+    n = len(prompts)
+    for p in prompts:
+        if p.size(1) >= cfg.max_seq_len:  # inference.py:263-266
+            raise ValueError(f"Input sequence length {p.size(1)} exceeds max_seq_len {cfg.max_seq_len}")
+    if not model._cache_setup_done:
+        model.setup_caches(max_batch_size=max(n, 1), max_seq_len=cfg.max_seq_len)
+    if n > model.max_batch_size:
+        raise ValueError(f"batch {n} exceeds max_batch_size {model.max_batch_size}")
+    mn = []
+    for p in prompts:
+        T = p.size(1)
+        m = max_new_tokens if max_new_tokens else cfg.max_seq_len - T
+        mn.append(min(m, cfg.max_seq_len - T))
+    slots = list(range(n))
+    seeds = list(seeds) if seeds is not None else [model.next_seed() for _ in range(n)]
+    samp = [model._sampling(temperature, top_p, top_k, seeds[i], use_ras) for i in range(n)]
+    model.prefill(slots, prompts, mn, samp)
+    remaining = max(mn) - 1
+    while remaining > 0:
+        step = min(poll_every, remaining)
+        model.decode(slots, step)
+        remaining -= step
+        if stop_on_im_end and all(model.poll_done(slots)):
+            break
+    outs = []
+    for i, p in enumerate(prompts):
+        frames, done = model.read(i)
+        seq = torch.cat([p.to("cpu", torch.int64), frames.t().to(torch.int64)], dim=1)
+        outs.append(seq.to(p.dtype) if p.dtype in (torch.int32, torch.int64) else seq)
+        model.release(i)
+    return outs

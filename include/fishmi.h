@@ -1,0 +1,206 @@
+/* fishmi.h -- C ABI of libfishmi.so: the MI355X (gfx950) hot path of fish-speech S2 inference.
+ *
+ * The reference (fishaudio/fish-speech) has no FFI: its seams are Python duck-typing
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout).  All pointers marked `dev` are device
+ * (HBM) addresses, e.g. torch `tensor.data_ptr()`; `stream` is a hipStream_t passed as
+ * void* (torch.cuda.current_stream().cuda_stream); 0 = the null stream.  Every function
+ * returns 0 on success or a negative FMI_E* code; fmi_last_error() gives the message
+ * (thread-local).  A handle is owned by one host thread at a time, like the reference's
+ * single llama worker thread (fish_speech/models/text2semantic/inference.py:748-799).
+ */
+#ifndef FISHMI_H
+#define FISHMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMI_OK 0
+#define FMI_EINVAL -1   /* bad argument / unsupported shape */
+#define FMI_EHIP -2     /* HIP runtime error */
+#define FMI_ESTATE -3   /* call out of order (weights not loaded, caches not set up ...) */
+#define FMI_ENOMEM -4   /* arena / page pool exhausted */
+
+int fmi_version(void);
+const char* fmi_last_error(void);
+/* gfx arch name of the current device ("gfx950") into buf. */
+int fmi_device_arch(char* buf, size_t n);
+
+/* ------------------------------------------------------------------ Dual-AR decoder ---- */
+
+/* Mirrors the fields of DualARModelArgs that inference reads
+ * (fish_speech/models/text2semantic/llama.py:27-193). */
+typedef struct fmi_dualar_config {
+  int32_t vocab_size, n_layer, n_head, n_local_heads, head_dim, dim, intermediate_size;
+  int32_t n_fast_layer, fast_dim, fast_n_head, fast_n_local_heads, fast_head_dim,
+      fast_intermediate_size;
+  int32_t codebook_size, num_codebooks;
+  int32_t semantic_begin_id, semantic_end_id, im_end_id;
+  int32_t max_seq_len;
+  int32_t attention_qk_norm, fast_attention_qk_norm;
+  int32_t scale_codebook_embeddings, norm_fastlayer_input;
+  float rope_base, norm_eps;
+} fmi_dualar_config;
+
+typedef struct fmi_dualar fmi_dualar;
+
+/* Bytes of device memory the packed weight arena needs for `cfg`. */
+int64_t fmi_dualar_arena_bytes(const fmi_dualar_config* cfg);
+
+/* Create a model over a caller-owned arena (one contiguous device allocation, so that a
+ * single RCCL broadcast replicates the weights: SURVEY.md 8e).  Replaces
+ * DualARTransformer.__init__ (llama.py:660-706). */
+int fmi_dualar_create(const fmi_dualar_config* cfg, void* arena_dev, int64_t arena_bytes,
+                      fmi_dualar** out);
+void fmi_dualar_destroy(fmi_dualar* h);
+
+/* Load one checkpoint tensor (row-major bf16, device or host pointer) by its state-dict
+ * name after the reference's key remap (llama.py:229-246), e.g.
+ * "layers.3.attention.wqkv.weight".  The library re-tiles it into the arena.  Replaces
+ * load_state_dict in BaseTransformer.from_pretrained (llama.py:480-594). */
+int fmi_dualar_load_tensor(fmi_dualar* h, const char* name, const void* src, int64_t rows,
+                           int64_t cols, int src_is_device, void* stream);
+/* Call once after all tensors are loaded (rank 0 before the broadcast) to build derived
+ * tables inside the arena (live LM-head rows, RoPE tables). */
+int fmi_dualar_finalize_weights(fmi_dualar* h, void* stream);
+/* Call on every rank after the arena content is in place (locally loaded or broadcast). */
+int fmi_dualar_weights_ready(fmi_dualar* h);
+
+/* KV-cache page pool + per-slot state for up to max_batch concurrent utterances of up to
+ * max_seq_len positions.  Replaces DualARTransformer.setup_caches (llama.py:307-324,708-722). */
+int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len);
+
+typedef struct fmi_sampling {
+  float temperature, top_p; /* rounded to bf16 inside, like inference.py:305-306 */
+  int32_t top_k;
+  uint32_t seed;    /* counter-based uniform generator, stream = slot */
+  int32_t use_ras;  /* 1 = repetition-aware sampling of inference.py:118-144 */
+} fmi_sampling;
+
+/* Start n utterances in slots slot_ids[i].  tokens_dev: int32, concatenated per utterance,
+ * each (T_i, 1+num_codebooks) row-major (position-major); lens[i] = T_i (host array).
+ * Runs the prompt through the slow transformer, then the first frame
+ * (decode_one_token_ar with previous_tokens=None, inference.py:324-334).
+ * max_new[i] bounds the pages reserved for the slot.  Replaces the prefill half of
+ * generate() (inference.py:243-334). */
+int fmi_dualar_prefill(fmi_dualar* h, int n, const int32_t* slot_ids, const int32_t* tokens_dev,
+                       const int32_t* lens, const int32_t* max_new, const fmi_sampling* samp,
+                       void* stream);
+
+/* Advance the given slots by n_frames frames (one hipGraph replay per frame; no host sync
+ * inside).  Replaces decode_n_tokens (inference.py:184-238) for a batch. A slot that emitted
+ * <|im_end|> or exhausted its reservation stops advancing. */
+int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frames, void* stream);
+
+/* Copy out what a slot generated so far: frames (n_frames, 1+num_codebooks) int32 into
+ * out_host (capacity max_frames); *n_frames_out = count, *done_out = 1 if the slot ended
+ * with <|im_end|>.  Synchronises the stream. */
+int fmi_dualar_read(fmi_dualar* h, int slot, int32_t* out_host, int max_frames, int* n_frames_out,
+                    int* done_out, void* stream);
+/* Non-blocking-ish poll of done flags for slots (host array of n ints). Synchronises. */
+int fmi_dualar_poll_done(fmi_dualar* h, int n, const int32_t* slot_ids, int32_t* done_host,
+                         void* stream);
+int fmi_dualar_release(fmi_dualar* h, int slot);
+
+/* Drop-in single-step seam = the `decode_one_token` callable
+ * (decode_one_token_ar, inference.py:96-181) for slot 0 semantics of the reference
+ * (batch 1).  x_dev: int32 (S, 1+ncb) position-major; pos0 = input_pos[0]; S>1 is a
+ * prefill call.  prev_dev: int32 (1+ncb, 10) RAS window or NULL.  out_dev: int32 (1+ncb).
+ * logits_out_dev (optional, bf16, n_live) / hidden_out_dev (optional, bf16, dim) expose
+ * forward_generate's results (llama.py:390-466) for the parity tests. */
+int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int pos0,
+                    const fmi_sampling* samp, const int32_t* prev_dev, int32_t frame_index,
+                    int32_t* out_dev, void* stream);
+
+/* Debug / parity taps (device pointers owned by the library, valid until the next call):
+ * live-row logits of the last slow step (bf16, [B][n_live_padded]), the vocab id of each
+ * live row (int32 [n_live]), the normed hidden (bf16 [B][dim]) and the fast logits of the
+ * last fast step (bf16 [B][codebook_size]). */
+int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* ld_logits,
+                          void** live_ids, void** hidden, void** fast_logits);
+/* If enabled, every fast step's logits are also copied to a trace buffer
+ * [B][num_codebooks][codebook_size] (bf16) returned here. */
+int fmi_dualar_set_trace(fmi_dualar* h, int enable, void** fast_trace);
+/* 1 = keep generating past <|im_end|> (fixed-length synthetic benchmarks). */
+int fmi_dualar_set_ignore_eos(fmi_dualar* h, int enable);
+/* Disable hipGraph replay (eager launches) -- used by tests/profiling. */
+int fmi_dualar_set_graph(fmi_dualar* h, int enable);
+/* Time of the last fmi_dualar_decode in ms measured with HIP events on `stream`, and the
+ * number of kernel launches per frame. */
+int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_frame);
+
+/* -------------------- op-level entry points (parity tests call the kernels directly) ---- */
+
+/* out[b][n] = sum_k xn[b][k] * W[n][k] with W row-major bf16 (re-tiled internally into
+ * scratch).  norm_w != NULL fuses RMSNorm(x) (llama.py:990-1001) in the prologue.
+ * epilogue: 0 = store bf16, 1 = bf16(residual + bf16(acc)) (llama.py:842),
+ * 2 = SwiGLU pairing silu(w1 x)*w3 x with W = [w1;w3] stacked (llama.py:979-987).
+ * force_path: 0 auto, 1 skinny (M<=16), 2 tiled GEMM. */
+int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_dev,
+                       const void* residual_dev, void* out_dev, int M, int N, int K, float eps,
+                       int epilogue, int force_path, void* stream);
+
+/* One sampler call on bf16 logits [B][ld] (n valid).  ids_dev: optional int32 map from row
+ * index to vocab id.  prev_dev: optional RAS window row (B x 10 int32) -- when given, the
+ * second (high-temperature) draw + selection of inference.py:118-144 is applied with
+ * [sem_begin, sem_end].  out_dev: int32 [B]. */
+int fmi_op_sample(const void* logits_dev, int B, int n, int ld, const int32_t* ids_dev,
+                  const fmi_sampling* samp, int frame, int draw, const int32_t* prev_dev,
+                  int sem_begin, int sem_end, int32_t* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------- codec (DAC) -- */
+
+typedef struct fmi_dac fmi_dac;
+
+/* Shape of fish_speech/configs/modded_dac_vq.yaml, overridable for small test models. */
+typedef struct fmi_dac_config {
+  int32_t encoder_dim;          /* 64 */
+  int32_t encoder_rates[4];     /* 2,4,8,8 */
+  int32_t decoder_dim;          /* 1536 */
+  int32_t decoder_rates[4];     /* 8,8,4,2 */
+  int32_t latent_dim;           /* 1024 = encoder_dim * 16 */
+  int32_t n_codebooks;          /* 9 residual */
+  int32_t codebook_size;        /* 1024 */
+  int32_t semantic_codebook_size; /* 4096 */
+  int32_t codebook_dim;         /* 8 */
+  int32_t downsample[2];        /* 2,2 */
+  int32_t tf_layers;            /* 8  (quantizer pre/post modules) */
+  int32_t tf_heads;             /* 16 */
+  int32_t tf_ffn;               /* 3072 */
+  int32_t tf_window;            /* 128 */
+  int32_t enc_tf_layers;        /* 4  (last encoder block) */
+  int32_t enc_tf_window;        /* 512 */
+  int32_t sample_rate;          /* 44100 */
+} fmi_dac_config;
+
+int64_t fmi_dac_arena_bytes(const fmi_dac_config* cfg);
+int fmi_dac_create(const fmi_dac_config* cfg, void* arena_dev, int64_t arena_bytes, fmi_dac** out);
+void fmi_dac_destroy(fmi_dac* h);
+/* fp32 tensors by codec.pth key, weight-norm pairs passed separately and
+ * folded inside (w = g*v/||v||).  ndim<=3, dims[] row-major. */
+int fmi_dac_load_tensor(fmi_dac* h, const char* name, const float* src, int ndim,
+                        const int64_t* dims, int src_is_device, void* stream);
+int fmi_dac_finalize_weights(fmi_dac* h, void* stream);
+int fmi_dac_weights_ready(fmi_dac* h);
+
+/* DAC.from_indices (fish_speech/models/dac/modded_dac.py:925-927): indices int64
+ * (B,1+n_codebooks,T) -> audio fp32 (B,1,T*frame_length).  Like the reference
+ * (rvq.py:354-359) the indices are clamped IN PLACE. */
+int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_out_dev,
+                   void* stream);
+/* DAC.encode (modded_dac.py:874-923): audio fp32 (B,1,N) (N already padded to a multiple of
+ * frame_length by the caller shim) -> indices int64 (B,1+n_codebooks,N/frame_length). */
+int fmi_dac_encode(fmi_dac* h, const float* audio_dev, int B, int N, int64_t* indices_out_dev,
+                   void* stream);
+int fmi_dac_frame_length(const fmi_dac* h);
+/* Debug tap: copy the quantizer-decode output z (B, latent_dim, 4T) fp32 of the last decode. */
+int fmi_dac_debug_z(fmi_dac* h, float** z_dev, int* C, int* L);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISHMI_H */

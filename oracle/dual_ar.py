@@ -1,0 +1,510 @@
+"""CPU oracle for the Dual-AR semantic-token decoder.  TEST INFRASTRUCTURE ONLY.
+
+This is a torch-CPU restatement of the algorithm in the reference's
+``fish_speech/models/text2semantic/llama.py`` and ``inference.py``.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
+product path (``fish_speech_amd``) never does and fails loudly without its HIP library.
+
+Parity pinning: the reference ships no tests or golden vectors, so this
+oracle is pinned against (a) the unmodified reference modules imported in the authoring
+container (``tests/test_oracle_vs_reference.py``, skipped where /root/reference is absent)
+and (b) fixtures those modules produced, committed under ``tests/golden/`` together with
+``oracle/gen_golden.py``.
+
+Numerical contract restated here (cast points; every op runs on torch CPU in the model dtype):
+  * RMSNorm (llama.py:990-1001): fp32 normalise -> cast to model dtype -> multiply by weight.
+  * q/k head norm (llama.py:862-864,901-903): ``torch.nn.RMSNorm`` = fp32 normalise * weight,
+    cast last.
+  * RoPE (llama.py:1004-1038): table rounded to bf16, adjacent-pair rotation in fp32, cast back.
+  * slow attention (llama.py:928-934): SDPA; inside the decode loop the MATH backend is forced
+    (inference.py:210), which upcasts q,k,v to fp32.  fast attention (llama.py:948-976) is an
+    explicit matmul/softmax chain in the model dtype.
+  * sampler (inference.py:43-93): everything in the logits dtype.
+
+Two places where the reference itself is not deterministic and this oracle pins a choice:
+  * ``torch.sort(descending=True)`` is unstable for more than 16 elements, so the order of equal
+    logits is unspecified upstream.  Here (and in the HIP sampler) ties are ordered by ascending
+    index.
+  * ``torch.rand_like`` cannot be reproduced on a GPU; the uniforms are an input here
+    (``uniform_fn``), and the HIP sampler's counter-based generator is restated in
+    ``fmi_uniform``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+RAS_WIN_SIZE = 10  # inference.py:49
+RAS_HIGH_TEMP = 1.0  # inference.py:50
+RAS_HIGH_TOP_P = 0.9  # inference.py:51
+
+
+@dataclass
+class DualARConfig:
+    """The subset of DualARModelArgs (llama.py:27-193) the inference path reads."""
+
+    vocab_size: int = 512
+    n_layer: int = 2
+    n_head: int = 4
+    n_local_heads: int = 2
+    head_dim: int = 32
+    dim: int = 128
+    intermediate_size: int = 256
+    rope_base: float = 1000000.0
+    norm_eps: float = 1e-6
+    max_seq_len: int = 256
+    attention_qk_norm: bool = True
+    codebook_size: int = 64
+    num_codebooks: int = 4
+    semantic_begin_id: int = 400
+    semantic_end_id: int = 463
+    im_end_id: int = 300
+    scale_codebook_embeddings: bool = True
+    norm_fastlayer_input: bool = True
+    n_fast_layer: int = 2
+    # the fast transformer shares widths with the slow one in S2 (llama.py:177-193)
+    fast_dim: int = 0
+    fast_n_head: int = 0
+    fast_n_local_heads: int = 0
+    fast_head_dim: int = 0
+    fast_intermediate_size: int = 0
+    fast_attention_qk_norm: Optional[bool] = None
+
+    def __post_init__(self):
+        self.fast_dim = self.fast_dim or self.dim
+        self.fast_n_head = self.fast_n_head or self.n_head
+        self.fast_n_local_heads = self.fast_n_local_heads or self.n_local_heads
+        self.fast_head_dim = self.fast_head_dim or self.head_dim
+        self.fast_intermediate_size = self.fast_intermediate_size or self.intermediate_size
+        if self.fast_attention_qk_norm is None:
+            self.fast_attention_qk_norm = self.attention_qk_norm
+
+    def reference_kwargs(self) -> dict:
+        """kwargs for the reference's DualARModelArgs (used only by the pinning tests)."""
+        return dict(
+            model_type="dual_ar", vocab_size=self.vocab_size, n_layer=self.n_layer,
+            n_head=self.n_head, n_local_heads=self.n_local_heads, head_dim=self.head_dim,
+            dim=self.dim, intermediate_size=self.intermediate_size, rope_base=self.rope_base,
+            norm_eps=self.norm_eps, max_seq_len=self.max_seq_len,
+            attention_qk_norm=self.attention_qk_norm, codebook_size=self.codebook_size,
+            num_codebooks=self.num_codebooks, semantic_begin_id=self.semantic_begin_id,
+            semantic_end_id=self.semantic_end_id,
+            scale_codebook_embeddings=self.scale_codebook_embeddings,
+            norm_fastlayer_input=self.norm_fastlayer_input, n_fast_layer=self.n_fast_layer,
+            tie_word_embeddings=True,
+        )
+
+
+def s2_pro_shaped_config(max_seq_len: int = 4096) -> DualARConfig:
+    """S2-Pro-shaped config.  ASSUMPTION: the real config.json is not in the
+    reference repo; widths follow README '4B slow / 400M fast / 10 codebooks' + Qwen3-4B."""
+    return DualARConfig(
+        vocab_size=155776, n_layer=36, n_head=32, n_local_heads=8, head_dim=128, dim=2560,
+        intermediate_size=9728, rope_base=1000000.0, norm_eps=1e-6, max_seq_len=max_seq_len,
+        attention_qk_norm=True, codebook_size=4096, num_codebooks=10,
+        semantic_begin_id=151678, semantic_end_id=151678 + 4095, im_end_id=151645,
+        n_fast_layer=4,
+    )
+
+
+# ----------------------------------------------------------------------------- weights
+
+
+def _block_keys(prefix: str, dim: int, n_head: int, n_kv: int, hd: int, ffn: int, qk_norm: bool):
+    shapes = {
+        f"{prefix}.attention.wqkv.weight": ((n_head + 2 * n_kv) * hd, dim),
+        f"{prefix}.attention.wo.weight": (dim, n_head * hd),
+        f"{prefix}.feed_forward.w1.weight": (ffn, dim),
+        f"{prefix}.feed_forward.w3.weight": (ffn, dim),
+        f"{prefix}.feed_forward.w2.weight": (dim, ffn),
+        f"{prefix}.ffn_norm.weight": (dim,),
+        f"{prefix}.attention_norm.weight": (dim,),
+    }
+    if qk_norm:
+        shapes[f"{prefix}.attention.q_norm.weight"] = (hd,)
+        shapes[f"{prefix}.attention.k_norm.weight"] = (hd,)
+    return shapes
+
+
+def state_shapes(cfg: DualARConfig) -> Dict[str, tuple]:
+    """State-dict keys after the reference's key remap (llama.py:229-246)."""
+    s: Dict[str, tuple] = {
+        "embeddings.weight": (cfg.vocab_size, cfg.dim),
+        "codebook_embeddings.weight": (cfg.codebook_size * cfg.num_codebooks, cfg.dim),
+        "norm.weight": (cfg.dim,),
+        "fast_embeddings.weight": (cfg.codebook_size, cfg.fast_dim),
+        "fast_norm.weight": (cfg.fast_dim,),
+        "fast_output.weight": (cfg.codebook_size, cfg.fast_dim),
+    }
+    for i in range(cfg.n_layer):
+        s.update(_block_keys(f"layers.{i}", cfg.dim, cfg.n_head, cfg.n_local_heads, cfg.head_dim,
+                             cfg.intermediate_size, cfg.attention_qk_norm))
+    for i in range(cfg.n_fast_layer):
+        s.update(_block_keys(f"fast_layers.{i}", cfg.fast_dim, cfg.fast_n_head,
+                             cfg.fast_n_local_heads, cfg.fast_head_dim,
+                             cfg.fast_intermediate_size, cfg.fast_attention_qk_norm))
+    return s
+
+
+def make_synthetic_state(cfg: DualARConfig, seed: int = 0, dtype=torch.bfloat16,
+                         matrix_std: float = 0.02, head_gain: float = 1.0,
+                         device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Seeded random weights with the reference's init scale (llama.py:468-477): N(0, 0.02) for
+    matrices/embeddings; norm weights are drawn around 1 so that they are exercised.
+    ``head_gain`` widens the logit spread (embeddings / fast_output rows) so that top-1 margins
+    are large against bf16 rounding in free-running parity tests."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = {}
+    for name, shape in state_shapes(cfg).items():
+        if len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = matrix_std * torch.randn(shape, generator=g)
+            if name in ("embeddings.weight", "fast_output.weight"):
+                t = t * head_gain
+        out[name] = t.to(dtype).to(device)
+    return out
+
+
+# ----------------------------------------------------------------------------- primitives
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """llama.py:990-1001: normalise in fp32, cast, then scale in the model dtype."""
+    xf = x.float()
+    y = xf * torch.rsqrt(torch.mean(xf * xf, dim=-1, keepdim=True) + eps)
+    return y.type_as(x) * w
+
+
+def head_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """llama.py:862-864: torch.nn.RMSNorm over head_dim (fp32 normalise*weight, cast last)."""
+    return F.rms_norm(x, (x.shape[-1],), w, eps)
+
+
+def rope_table(seq_len: int, n_elem: int, base: float) -> torch.Tensor:
+    """llama.py:1004-1023: (seq, n_elem/2, 2) cos/sin table, ROUNDED TO bf16."""
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
+    ang = torch.outer(torch.arange(seq_len), freqs)
+    return torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
+
+
+def apply_rope(x: torch.Tensor, tab: torch.Tensor) -> torch.Tensor:
+    """llama.py:1026-1038.  x: (B,S,H,D); tab: (S,D/2,2).  Adjacent pairs rotate, fp32 math."""
+    xs = x.float().reshape(*x.shape[:-1], -1, 2)
+    t = tab.view(1, xs.size(1), 1, xs.size(3), 2)
+    re = xs[..., 0] * t[..., 0] - xs[..., 1] * t[..., 1]
+    im = xs[..., 1] * t[..., 0] + xs[..., 0] * t[..., 1]
+    return torch.stack([re, im], dim=-1).flatten(3).type_as(x)
+
+
+def fast_attention(q, k, v, mask):
+    """llama.py:948-976: explicit attention entirely in the model dtype (used by the fast AR)."""
+    scale = 1 / math.sqrt(q.size(-1))
+    bias = torch.zeros(1, 1, q.size(-2), k.size(-2), dtype=q.dtype)
+    bias = torch.where(mask.logical_not(), float("-inf"), bias)
+    w = q @ k.transpose(-2, -1) * scale
+    w = w + bias
+    w = torch.softmax(w, dim=-1)
+    return w @ v
+
+
+def slow_attention(q, k, v, mask, math_backend: bool):
+    """llama.py:928-934.  The decode loop forces the MATH backend (inference.py:210); the
+    prefill call runs under the default CPU backend selection."""
+    if math_backend:
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+
+        with sdpa_kernel(SDPBackend.MATH):
+            return F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    return F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+
+
+# ----------------------------------------------------------------------------- model
+
+
+class DualAROracle:
+    """Functional restatement of DualARTransformer's generate-time surface (llama.py:660-828)."""
+
+    def __init__(self, cfg: DualARConfig, state: Dict[str, torch.Tensor]):
+        self.cfg = cfg
+        self.w = state
+        self.dtype = state["embeddings.weight"].dtype
+        self.freqs = rope_table(cfg.max_seq_len, cfg.head_dim, cfg.rope_base)
+        self.fast_freqs = rope_table(cfg.num_codebooks, cfg.fast_head_dim, cfg.rope_base)
+        self.max_seq_len = -1
+        self.kv: List[tuple] = []
+        self.fast_kv: List[tuple] = []
+        # hooks for the parity tests: last slow logits / hidden, list of fast logits
+        self.trace: Optional[dict] = None
+
+    # llama.py:307-324,708-722
+    def setup_caches(self, max_batch_size: int, max_seq_len: int):
+        cfg = self.cfg
+        max_seq_len = max_seq_len + (-max_seq_len) % 8
+        self.max_seq_len = max_seq_len
+        z = lambda h, s, d: torch.zeros(max_batch_size, h, s, d, dtype=self.dtype)
+        self.kv = [(z(cfg.n_local_heads, max_seq_len, cfg.head_dim),
+                    z(cfg.n_local_heads, max_seq_len, cfg.head_dim)) for _ in range(cfg.n_layer)]
+        self.fast_kv = [(z(cfg.fast_n_local_heads, cfg.num_codebooks, cfg.fast_head_dim),
+                         z(cfg.fast_n_local_heads, cfg.num_codebooks, cfg.fast_head_dim))
+                        for _ in range(cfg.n_fast_layer)]
+
+    # llama.py:400-420
+    def embed(self, inp: torch.Tensor) -> torch.Tensor:
+        cfg, w = self.cfg, self.w
+        parts = [F.embedding(inp[:, i + 1] + i * cfg.codebook_size, w["codebook_embeddings.weight"])
+                 for i in range(cfg.num_codebooks)]
+        vq = torch.stack(parts, dim=1).sum(dim=1)
+        is_sem = (inp[:, 0] >= cfg.semantic_begin_id) & (inp[:, 0] <= cfg.semantic_end_id)
+        vq[~is_sem] = 0
+        x = F.embedding(inp[:, 0], w["embeddings.weight"]) + vq
+        if cfg.scale_codebook_embeddings:
+            x = torch.where(is_sem.unsqueeze(-1).expand_as(x), x / math.sqrt(cfg.num_codebooks + 1), x)
+        return x
+
+    def _block(self, prefix, x, tab, mask, pos, kv, n_head, n_kv, hd, qk_norm, slow, math_backend):
+        w, eps = self.w, self.cfg.norm_eps
+        B, S, _ = x.shape
+        h_in = rms_norm(x, w[f"{prefix}.attention_norm.weight"], eps)
+        qkv = F.linear(h_in, w[f"{prefix}.attention.wqkv.weight"])
+        q, k, v = qkv.split([n_head * hd, n_kv * hd, n_kv * hd], dim=-1)
+        q = q.view(B, S, n_head, hd)
+        k = k.view(B, S, n_kv, hd)
+        v = v.view(B, S, n_kv, hd)
+        if qk_norm:
+            q = head_norm(q, w[f"{prefix}.attention.q_norm.weight"], eps)
+            k = head_norm(k, w[f"{prefix}.attention.k_norm.weight"], eps)
+        q = apply_rope(q, tab)
+        k = apply_rope(k, tab)
+        q, k, v = (t.transpose(1, 2) for t in (q, k, v))
+        kc, vc = kv  # llama.py:205-214: scatter at input_pos, attend over the WHOLE cache
+        kc[:, :, pos] = k
+        vc[:, :, pos] = v
+        rep = n_head // n_kv
+        kk = kc.repeat_interleave(rep, dim=1)
+        vv = vc.repeat_interleave(rep, dim=1)
+        y = slow_attention(q, kk, vv, mask, math_backend) if slow else fast_attention(q, kk, vv, mask)
+        y = y.transpose(1, 2).contiguous().view(B, S, n_head * hd)
+        h = x + F.linear(y, w[f"{prefix}.attention.wo.weight"])
+        f_in = rms_norm(h, w[f"{prefix}.ffn_norm.weight"], eps)
+        ff = F.linear(F.silu(F.linear(f_in, w[f"{prefix}.feed_forward.w1.weight"]))
+                      * F.linear(f_in, w[f"{prefix}.feed_forward.w3.weight"]),
+                      w[f"{prefix}.feed_forward.w2.weight"])
+        return h + ff
+
+    # llama.py:390-466 + 819-828
+    def forward_generate(self, inp: torch.Tensor, input_pos: torch.Tensor, math_backend: bool):
+        cfg = self.cfg
+        x = self.embed(inp)
+        pos = input_pos.long()
+        causal = torch.tril(torch.ones(self.max_seq_len, self.max_seq_len, dtype=torch.bool))
+        mask = causal[None, None, pos, : self.max_seq_len]
+        tab = self.freqs[pos]
+        for i in range(cfg.n_layer):
+            x = self._block(f"layers.{i}", x, tab, mask, pos, self.kv[i], cfg.n_head,
+                            cfg.n_local_heads, cfg.head_dim, cfg.attention_qk_norm, True,
+                            math_backend)
+        if x.size(1) > 1:
+            x = x[:, -1:]
+        slow_out = rms_norm(x, self.w["norm.weight"], cfg.norm_eps)
+        logits = F.linear(slow_out, self.w["embeddings.weight"])  # tied head, llama.py:454-455
+        hidden = slow_out if cfg.norm_fastlayer_input else x
+        return logits, hidden
+
+    # llama.py:799-817
+    def forward_generate_fast(self, x: torch.Tensor, input_pos: torch.Tensor):
+        cfg = self.cfg
+        x = x.view(x.shape[0], 1, -1)
+        pos = input_pos.long()
+        n = cfg.num_codebooks
+        mask = torch.tril(torch.ones(n, n, dtype=torch.bool))[None, None, pos, :n]
+        tab = self.fast_freqs[pos]
+        for i in range(cfg.n_fast_layer):
+            x = self._block(f"fast_layers.{i}", x, tab, mask, pos, self.fast_kv[i], cfg.fast_n_head,
+                            cfg.fast_n_local_heads, cfg.fast_head_dim, cfg.fast_attention_qk_norm,
+                            False, False)
+        out = rms_norm(x, self.w["fast_norm.weight"], cfg.norm_eps)
+        return F.linear(out, self.w["fast_output.weight"])
+
+    def fast_embeddings(self, a: torch.Tensor) -> torch.Tensor:
+        return F.embedding(a, self.w["fast_embeddings.weight"])
+
+
+# ----------------------------------------------------------------------------- sampling
+
+UniformFn = Callable[[int, torch.dtype], torch.Tensor]
+"""uniform_fn(n, dtype) -> the n uniforms consumed by one draw (stands in for torch.rand_like)."""
+
+
+def fmi_uniform_u8(seed: int, stream: int, frame: int, draw: int, n: int) -> np.ndarray:
+    """The HIP sampler's counter-based generator (csrc/sampler.hip `fmi_rand_u8`), restated.
+    Returns n bytes; the uniform is byte/256, matching the 8 random mantissa bits torch's CPU
+    ``rand_like`` yields for bf16."""
+    i = np.arange(n, dtype=np.uint64)
+    x = (np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x9E3779B1)
+         + np.uint64(stream) * np.uint64(0x85EBCA77)
+         + np.uint64(frame) * np.uint64(0xC2B2AE3D)
+         + np.uint64(draw) * np.uint64(0x27D4EB2F)
+         + i * np.uint64(0x165667B1)) & np.uint64(0xFFFFFFFF)
+    x = x.astype(np.uint32)
+    # murmur3 finaliser
+    x ^= x >> np.uint32(16)
+    x = (x.astype(np.uint64) * np.uint64(0x85EBCA6B) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    x ^= x >> np.uint32(13)
+    x = (x.astype(np.uint64) * np.uint64(0xC2B2AE35) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return (x >> np.uint32(24)).astype(np.uint8)
+
+
+def logits_to_probs(logits: torch.Tensor, temperature: torch.Tensor, top_p: torch.Tensor,
+                    top_k: int) -> torch.Tensor:
+    """inference.py:54-77.  Top-p/top-k mask is computed on the UN-tempered logits; temperature is
+    applied afterwards.  Ties are ordered by ascending index (see module docstring)."""
+    sl, si = torch.sort(logits, descending=True, stable=True)
+    cum = torch.cumsum(torch.softmax(sl, dim=-1), dim=-1)
+    rank = torch.arange(sl.shape[-1])
+    remove = (cum > top_p) | (rank >= top_k)
+    remove[0] = False
+    remove_v = remove.scatter(dim=-1, index=si, src=remove)
+    logits = torch.where(remove_v, float("-inf"), logits)
+    logits = logits / torch.clip(temperature, min=1e-5)
+    return torch.softmax(logits, dim=-1)
+
+
+def draw(probs: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """inference.py:43-46: exponential race, argmax(probs / -log(u)) as int32."""
+    q = -torch.log(u.to(probs.dtype))
+    return torch.argmax(probs / q, dim=-1, keepdim=True).to(torch.int)
+
+
+def sample(logits: torch.Tensor, temperature, top_p, top_k: int, uniform_fn: UniformFn):
+    """inference.py:80-93.  NOTE logits[0, -1]: batch row 0 only."""
+    probs = logits_to_probs(logits[0, -1], temperature, top_p, top_k)
+    return draw(probs, uniform_fn(probs.shape[-1], probs.dtype))
+
+
+def torch_uniform_fn(n: int, dtype) -> torch.Tensor:
+    return torch.rand(n, dtype=torch.float32).to(dtype) if dtype == torch.float32 else \
+        torch.rand_like(torch.empty(n, dtype=dtype))
+
+
+class FmiUniform:
+    """Uniform source that replays the HIP sampler's generator for one utterance stream."""
+
+    def __init__(self, seed: int, stream: int = 0):
+        self.seed, self.stream, self.frame, self.draw_idx = seed, stream, 0, 0
+
+    def next_frame(self):
+        self.frame += 1
+        self.draw_idx = 0
+
+    def __call__(self, n: int, dtype) -> torch.Tensor:
+        b = fmi_uniform_u8(self.seed, self.stream, self.frame, self.draw_idx, n)
+        self.draw_idx += 1
+        return (torch.from_numpy(b.astype(np.float32)) / 256.0).to(dtype)
+
+
+# ----------------------------------------------------------------------------- frame step + loop
+
+
+def semantic_logit_bias(cfg: DualARConfig, dtype) -> torch.Tensor:
+    """inference.py:310-320."""
+    b = torch.full((1, 1, cfg.vocab_size), float("-inf"), dtype=dtype)
+    b[0, 0, cfg.semantic_begin_id: cfg.semantic_end_id + 1] = 0.0
+    b[0, 0, cfg.im_end_id] = 0.0
+    return b
+
+
+def decode_one_token(model: DualAROracle, x: torch.Tensor, input_pos: torch.Tensor, temperature,
+                     top_p, top_k: int, bias: torch.Tensor, previous_tokens: Optional[torch.Tensor],
+                     uniform_fn: UniformFn, math_backend: bool) -> torch.Tensor:
+    """inference.py:96-181 (one frame = slow step + 2 constrained draws + RAS + fast chain)."""
+    cfg = model.cfg
+    logits, hidden = model.forward_generate(x, input_pos, math_backend)
+    biased = logits + bias
+    tok_n = sample(biased, temperature, top_p, top_k, uniform_fn)
+    hi_t = torch.tensor(RAS_HIGH_TEMP, dtype=temperature.dtype)
+    hi_p = torch.tensor(RAS_HIGH_TOP_P, dtype=top_p.dtype)
+    tok_h = sample(biased, hi_t, hi_p, top_k, uniform_fn)
+    if previous_tokens is not None:
+        in_window = (previous_tokens[0] == tok_n).any()
+        is_sem = (tok_n >= cfg.semantic_begin_id) & (tok_n <= cfg.semantic_end_id)
+        tok_n = torch.where(in_window & is_sem, tok_h, tok_n)
+    codebooks = [tok_n]
+    if model.trace is not None:
+        model.trace.setdefault("slow_logits", []).append(logits[0, -1].clone())
+        model.trace.setdefault("hidden", []).append(hidden[0, -1].clone())
+        model.trace.setdefault("fast_logits", []).append([])
+    model.forward_generate_fast(hidden, torch.tensor([0]))  # logits discarded (inference.py:148-149)
+    a = torch.clamp(tok_n - cfg.semantic_begin_id, min=0, max=cfg.codebook_size - 1)
+    h = model.fast_embeddings(a)
+    codebooks.append(a)
+    for cb in range(1, cfg.num_codebooks):
+        lg = model.forward_generate_fast(h, torch.tensor([cb]))
+        if model.trace is not None:
+            model.trace["fast_logits"][-1].append(lg[0, -1].clone())
+        a = sample(lg, temperature, top_p, top_k, uniform_fn)
+        h = model.fast_embeddings(a)
+        codebooks.append(a)
+    return torch.stack(codebooks, dim=1).T
+
+
+def generate(model: DualAROracle, prompt: torch.Tensor, max_new_tokens: int, temperature: float = 1.0,
+             top_p: float = 0.9, top_k: int = 30, uniform_fn: Optional[UniformFn] = None,
+             stop_on_im_end: bool = True) -> torch.Tensor:
+    """inference.py:243-359 + 184-238.  prompt: (1+ncb, T) integer; returns (1+ncb, T+n)."""
+    cfg = model.cfg
+    uniform_fn = uniform_fn or torch_uniform_fn
+    T = prompt.size(1)
+    if T >= cfg.max_seq_len:
+        raise ValueError(f"Input sequence length {T} exceeds max_seq_len {cfg.max_seq_len}")
+    if max_new_tokens:
+        if T + max_new_tokens > cfg.max_seq_len:
+            max_new_tokens = cfg.max_seq_len - T
+    else:
+        max_new_tokens = cfg.max_seq_len - T
+    if model.max_seq_len < 0:
+        model.setup_caches(1, cfg.max_seq_len)
+    dtype = model.dtype
+    ncb1 = 1 + cfg.num_codebooks
+    temp = torch.tensor(temperature, dtype=dtype)
+    tp = torch.tensor(top_p, dtype=dtype)
+    bias = semantic_logit_bias(cfg, dtype)
+    first = decode_one_token(model, prompt.view(1, ncb1, -1), torch.arange(0, T), temp, tp, top_k,
+                             bias, None, uniform_fn, math_backend=False)
+    frames = [first]
+    window = torch.zeros((ncb1, RAS_WIN_SIZE), dtype=torch.int)
+    cur = first.view(1, ncb1, -1)
+    pos = torch.tensor([T], dtype=torch.int)
+    for _ in range(max_new_tokens - 1):
+        if hasattr(uniform_fn, "next_frame"):
+            uniform_fn.next_frame()
+        nxt = decode_one_token(model, cur, pos, temp, tp, top_k, bias, window, uniform_fn,
+                               math_backend=True).clone()
+        pos += 1
+        cur = nxt.view(1, ncb1, -1)
+        window = window.roll(-1, dims=1)
+        window[:, -1] = nxt.view(ncb1, -1)[:, 0]
+        frames.append(nxt)
+        if stop_on_im_end and cur[0, 0, -1] == cfg.im_end_id:
+            break
+    return torch.cat([prompt.to(torch.int64)] + [f.to(torch.int64) for f in frames], dim=1)
+
+
+def make_prompt(cfg: DualARConfig, T: int, seed: int, n_semantic: int = 0) -> torch.Tensor:
+    """Synthetic (1+ncb, T) prompt: text ids in row 0, zero code rows; the last
+    ``n_semantic`` positions carry semantic ids + codes (voice-clone shaped)."""
+    g = torch.Generator().manual_seed(seed)
+    p = torch.zeros((1 + cfg.num_codebooks, T), dtype=torch.int64)
+    hi = min(cfg.semantic_begin_id, cfg.vocab_size)
+    p[0] = torch.randint(0, hi, (T,), generator=g)
+    if n_semantic:
+        codes = torch.randint(0, cfg.codebook_size, (cfg.num_codebooks, n_semantic), generator=g)
+        p[1:, T - n_semantic:] = codes
+        p[0, T - n_semantic:] = codes[0] + cfg.semantic_begin_id
+    return p
