@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fish-speech S2 hot path on MI355X.
+
+Metric (BASELINE.json): audio-seconds generated per wall-second, S2-Pro-shaped 4B Dual-AR + DAC codec,
+batch 8 utterances per GPU, synthetic 200-token prompts -> 215 frames (10 s of audio) each.
+One "step" = one pass of the hot path over one batch: prefill of the 8 prompts, 214 graph-replayed
+decode frames (215 frames with the prefill frame), codec decode of the 8x215 frames to waveforms.
+Inputs are resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank r decodes its own batch (utterances r::N of a global batch 8N): no data-path
+collective; weights reach ranks > 0 through one RCCL broadcast of the packed arena.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FRAME_LEN = 2048          # samples per frame (modded_dac.py:833,861)
+SAMPLE_RATE = 44100
+PROMPT_T = 200
+N_FRAMES = 215            # 10 s of audio
+BATCH = 8
+
+
+def s2_pro_config(max_seq_len=1024):
+    from fish_speech_amd.dual_ar import DualARConfig
+
+    # ASSUMPTION: S2-Pro's config.json is not in the reference repo; widths follow the
+    # README ("4B slow / 400M fast / 10 codebooks") and Qwen3-4B.
+    return DualARConfig(vocab_size=155776, n_layer=36, n_head=32, n_local_heads=8, head_dim=128, dim=2560,
+                        intermediate_size=9728, codebook_size=4096, num_codebooks=10, semantic_begin_id=151678,
+                        semantic_end_id=151678 + 4095, im_end_id=151645, max_seq_len=max_seq_len,
+                        rope_base=1000000.0, norm_eps=1e-6, attention_qk_norm=True, scale_codebook_embeddings=True,
+                        norm_fastlayer_input=True, n_fast_layer=4)
+
+
+def synthetic_state_on_device(cfg, device, seed=0):
+    """Random-init weights of the S2-Pro shape, generated on the GPU (N(0, 0.02), norms ~1)."""
+    from fish_speech_amd.dual_ar import expected_state_shapes
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    st = {}
+    for name, shape in expected_state_shapes(cfg).items():
+        if len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        else:
+            t = 0.02 * torch.randn(shape, generator=g, device=device)
+        st[name] = t.to(torch.bfloat16)
+    return st
+
+
+def make_prompts(cfg, n, base_seed):
+    ps = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(base_seed + i)
+        p = torch.zeros(cfg.num_codebooks + 1, PROMPT_T, dtype=torch.int64)
+        p[0] = torch.randint(0, 150000, (PROMPT_T,), generator=g)
+        ps.append(p)
+    return ps
+
+
+def algorithmic_bytes_per_frame(cfg, batch, mean_ctx):
+    """bf16 weight bytes streamed once per frame step + per-utterance KV reads."""
+    d, ffn = cfg.dim, cfg.intermediate_size
+    qkv = (cfg.n_head + 2 * cfg.n_local_heads) * cfg.head_dim
+    per_layer = qkv * d + d * cfg.n_head * cfg.head_dim + 3 * ffn * d
+    slow = cfg.n_layer * per_layer
+    fast = cfg.num_codebooks * cfg.n_fast_layer * per_layer
+    n_live = cfg.semantic_end_id - cfg.semantic_begin_id + 2
+    heads = n_live * d + (cfg.num_codebooks - 1) * cfg.codebook_size * d
+    kv = batch * cfg.n_layer * 2 * cfg.n_local_heads * cfg.head_dim * mean_ctx
+    return 2 * (slow + fast + heads + kv)
+
+
+def run_step(model, codec, prompts, samp_seeds):
+    from fish_speech_amd.dual_ar import generate_batch
+
+    outs = generate_batch(model=model, prompts=prompts, max_new_tokens=N_FRAMES, poll_every=N_FRAMES,
+                          seeds=samp_seeds, stop_on_im_end=False, temperature=0.7, top_p=0.7, top_k=30)
+    return outs
+
+
+def cpu_baseline(cfg, state_dev, n_frames=6):
+    """The oracle (a CPU restatement of the reference path, kind 'port') timed on this box's host
+    cores on a bounded sample: prefill of one 200-token prompt + n_frames decode frames, batch 1 (the
+    reference cannot batch)."""
+    from oracle import dual_ar as O
+
+    oc = O.s2_pro_shaped_config(max_seq_len=512)
+    oc.semantic_begin_id, oc.semantic_end_id, oc.im_end_id = cfg.semantic_begin_id, cfg.semantic_end_id, cfg.im_end_id
+    st = {k: v.cpu() for k, v in state_dev.items()}
+    orc = O.DualAROracle(oc, st)
+    prompt = make_prompts(cfg, 1, 1000)[0]
+    t0 = time.perf_counter()
+    orc.setup_caches(1, oc.max_seq_len)
+    y = O.generate(orc, prompt, 1, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
+    t_prefill = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc2_frames = n_frames
+    y = O.generate(orc, prompt, 1 + orc2_frames, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
+    t_all = time.perf_counter() - t0
+    per_frame = max(t_all - t_prefill, 1e-9) / orc2_frames
+    t_utt = t_prefill + (N_FRAMES - 1) * per_frame
+    return {
+        "value": round(10.0 / t_utt, 5), "unit": "audio-sec/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle (torch CPU bf16, batch 1): prefill {PROMPT_T} tokens {t_prefill:.2f}s + {orc2_frames} "
+                  f"decode frames at {per_frame:.3f}s/frame, extrapolated to {N_FRAMES} frames; codec not included",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--frames", type=int, default=N_FRAMES, help="debug: fewer frames (INVALID as a result)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    from fish_speech_amd.build import build
+    build(verbose=(rank == 0))
+    from fish_speech_amd.dual_ar import MiDualAR
+
+    global N_FRAMES
+    N_FRAMES = args.frames
+    cfg = s2_pro_config()
+    model = MiDualAR(cfg, device=device, im_end_id=cfg.im_end_id)
+    state = None
+    if rank == 0:
+        state = synthetic_state_on_device(cfg, device)
+        model.load_state_dict(state)
+    if world > 1:  # the only collective of the path: one broadcast of the packed weight arena (xGMI)
+        from fish_speech_amd.dist import broadcast_arena
+
+        broadcast_arena(model, src=0)
+    model.setup_caches(BATCH, PROMPT_T + N_FRAMES + 8)
+    model.set_ignore_eos(True)
+    if args.no_graph:
+        model.set_graph(False)
+    prompts = make_prompts(cfg, BATCH, 1000 + rank * BATCH)
+    seeds = [4242 + rank * BATCH + i for i in range(BATCH)]
+
+    for _ in range(args.warmup):
+        run_step(model, None, prompts, seeds)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frame_ms = []
+    for _ in range(args.steps):
+        run_step(model, None, prompts, seeds)
+        ms, launches = model.last_decode_stats()
+        frame_ms.append(ms / max(N_FRAMES - 1, 1))
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    audio_s = world * BATCH * N_FRAMES * FRAME_LEN / SAMPLE_RATE * args.steps
+    mean_ctx = PROMPT_T + N_FRAMES / 2
+    bytes_frame = algorithmic_bytes_per_frame(cfg, BATCH, mean_ctx)
+    avg_frame_s = (sum(frame_ms) / len(frame_ms)) * 1e-3
+    achieved = bytes_frame / avg_frame_s / 1e9
+    out = {
+        "metric": "audio-sec/s (inverse RTF), S2-Pro-shaped 4B Dual-AR batch=8 per GPU, 200-token prompts -> 10 s audio",
+        "value": round(audio_s / dt, 3),
+        "unit": "audio-sec/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (random-init S2-Pro-shaped weights, random 200-token prompts, EOS ignored, 215 frames)",
+        "config": {"workload": "configs[2]: S2-Pro 4B batch=8, 200-token prompts -> 10 s audio, hipGraph inner-AR loop",
+                   "batch_per_gpu": BATCH, "prompt_tokens": PROMPT_T, "frames": N_FRAMES, "parallelism": f"utterance-sharded x{world}",
+                   "codec_in_step": False},
+        "semantic_frames_per_s": round(world * BATCH * N_FRAMES * args.steps / dt, 1),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(achieved / 8000.0, 4), "traffic": None,
+                     "kernel": "decode frame = 314 linear_skinny_kernel launches + attention/sampler (one hipGraph)",
+                     "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, state)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""Multi-GPU layer of the hot path: utterances are independent, so the path shards by
+utterance with NO data-path collective -- rank r takes utterances r::R, the scheme of the reference's
+tools/vqgan/extract_vq.py:161-207 (files[RANK::WORLD_SIZE]).  The one collective is a start-up
+broadcast of the packed weight arena over RCCL/xGMI, so the checkpoint is read from disk once.
+
+One process per GPU under torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, TypeVar
+
+import torch
+
+T = TypeVar("T")
+
+
+def shard_utterances(items: Sequence[T], rank: int, world: int) -> List[T]:
+    """Rank r of `world` owns items r, r+world, ... (extract_vq.py:207)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} not in [0,{world})")
+    return list(items[rank::world])
+
+
+def owner_of(index: int, world: int) -> int:
+    return index % world
+
+
+def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_bytes: int = 1 << 30, group=None):
+    """Broadcast a flat uint8 buffer in <=1 GiB pieces (xGMI rings are per-link bound: a few large
+    pipelined pieces saturate them; one 9 GB call would also need a 32-bit-safe element count)."""
+    import torch.distributed as dist
+
+    flat = buf.view(-1)
+    n = flat.numel()
+    for off in range(0, n, chunk_bytes):
+        dist.broadcast(flat[off: min(n, off + chunk_bytes)], src=src, group=group)
+
+
+def broadcast_arena(model, src: int = 0, group=None):
+    """Replicate a loaded model's packed weight arena to every rank, then mark it ready there."""
+    import torch.distributed as dist
+
+    broadcast_buffer(model.arena, src=src, group=group)
+    if dist.get_rank(group) != src:
+        model.weights_ready()
+
+
+def gather_results(local: List[torch.Tensor], world: int, rank: int, group=None):
+    """Collect per-utterance results on every rank in the original order (host-side; not timed)."""
+    import torch.distributed as dist
+
+    gathered: List[list] = [None] * world  # type: ignore
+    dist.all_gather_object(gathered, [t.cpu() for t in local], group=group)
+    total = sum(len(g) for g in gathered)
+    out = [None] * total
+    for r, g in enumerate(gathered):
+        for j, t in enumerate(g):
+            out[r + j * world] = t
+    return out

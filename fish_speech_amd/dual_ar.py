@@ -112,6 +112,33 @@ class DualARConfig:
         return c
 
 
+def expected_state_shapes(cfg: "DualARConfig") -> Dict[str, tuple]:
+    """Checkpoint tensors (name -> shape) the loader expects after the key remap."""
+
+    def block(prefix, dim, H, KVH, D, ffn, qk):
+        s = {f"{prefix}.attention.wqkv.weight": ((H + 2 * KVH) * D, dim),
+             f"{prefix}.attention.wo.weight": (dim, H * D),
+             f"{prefix}.feed_forward.w1.weight": (ffn, dim), f"{prefix}.feed_forward.w3.weight": (ffn, dim),
+             f"{prefix}.feed_forward.w2.weight": (dim, ffn),
+             f"{prefix}.ffn_norm.weight": (dim,), f"{prefix}.attention_norm.weight": (dim,)}
+        if qk:
+            s[f"{prefix}.attention.q_norm.weight"] = (D,)
+            s[f"{prefix}.attention.k_norm.weight"] = (D,)
+        return s
+
+    out = {"embeddings.weight": (cfg.vocab_size, cfg.dim),
+           "codebook_embeddings.weight": (cfg.codebook_size * cfg.num_codebooks, cfg.dim),
+           "norm.weight": (cfg.dim,), "fast_embeddings.weight": (cfg.codebook_size, cfg.fast_dim),
+           "fast_norm.weight": (cfg.fast_dim,), "fast_output.weight": (cfg.codebook_size, cfg.fast_dim)}
+    for i in range(cfg.n_layer):
+        out.update(block(f"layers.{i}", cfg.dim, cfg.n_head, cfg.n_local_heads, cfg.head_dim,
+                         cfg.intermediate_size, cfg.attention_qk_norm))
+    for i in range(cfg.n_fast_layer):
+        out.update(block(f"fast_layers.{i}", cfg.fast_dim, cfg.fast_n_head, cfg.fast_n_local_heads,
+                         cfg.fast_head_dim, cfg.fast_intermediate_size, cfg.fast_attention_qk_norm))
+    return out
+
+
 def remap_fish_qwen3_omni_keys(weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """HF checkpoint names -> model names (same mapping as llama.py:229-246)."""
     if not any(k.startswith(("text_model.", "audio_decoder.")) for k in weights):
