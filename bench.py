@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--frames", type=int, default=N_FRAMES, help="debug: fewer frames (INVALID as a result)")
+    ap.add_argument("--frames", type=int, default=215, help="debug: fewer frames (INVALID as a result)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,8 +146,7 @@ def main():
     build(verbose=(rank == 0))
     from fish_speech_amd.dual_ar import MiDualAR
 
-    global N_FRAMES
-    N_FRAMES = args.frames
+    globals()["N_FRAMES"] = args.frames
     cfg = s2_pro_config()
     model = MiDualAR(cfg, device=device, im_end_id=cfg.im_end_id)
     state = None

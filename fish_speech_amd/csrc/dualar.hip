@@ -57,7 +57,7 @@ struct fmi_dualar {
   std::vector<int> free_pages;
   std::vector<std::vector<int>> slot_pages;
   Workspace ws;
-  bf16_t *hn = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
+  bf16_t *hn = nullptr, *hf = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
   bool trace = false, use_graph = true, ignore_eos = false;
   std::map<int, hipGraphExec_t> graphs;
   void* staging = nullptr;
@@ -278,7 +278,8 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
 int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStream_t s) {
   const fmi_dualar_config& c = h->cfg;
   const int dim = c.dim;
-  FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s));
+  // hn = normed hidden (head input, parity tap); hf = its copy that fast step 0 transforms in place
+  FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s, h->hf));
   h->launches += 1;
   FMI_CHECK(linear(h, h->hn, dim, h->head_live, nullptr, nullptr, 0, h->logits, h->n_live_pad, B, h->n_live_pad, dim,
                    EPI_STORE, s));
@@ -290,11 +291,9 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   FMI_CHECK(launch_sample(sa, s));
   h->launches += 1;
   // fast step 0 on the hidden state; its logits are discarded (inference.py:148-149)
-  bf16_t* f0 = h->hn;
-  if (!c.norm_fastlayer_input) {
-    FMI_CHECK_HIP(hipMemcpyAsync(h->ws.xn, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
-    f0 = h->ws.xn;
-  }
+  bf16_t* f0 = h->hf;
+  if (!c.norm_fastlayer_input)
+    FMI_CHECK_HIP(hipMemcpyAsync(h->hf, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
   for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, f0, B, 0, row_slot, s));
   for (int cb = 1; cb < c.num_codebooks; ++cb) {
     for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, B, cb, row_slot, s));
@@ -432,7 +431,7 @@ void fmi_dualar_destroy(fmi_dualar* h) {
   for (auto p : h->fvc) hipFree(p);
   void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
                   h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
-                  h->hn, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging};
+                  h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging};
   for (void* p : ptrs)
     if (p) hipFree(p);
   hipEventDestroy(h->ev_in);
@@ -613,6 +612,7 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
   FMI_CHECK(dev_alloc(&st.block_table, (int64_t)max_batch * h->max_pages));
   FMI_CHECK(dev_alloc(&h->hn, (int64_t)max_batch * c.dim));
   FMI_CHECK(dev_alloc(&h->xl, (int64_t)max_batch * c.dim));
+  FMI_CHECK(dev_alloc(&h->hf, (int64_t)max_batch * c.dim));
   FMI_CHECK(dev_alloc(&h->xf, (int64_t)max_batch * c.fast_dim));
   FMI_CHECK(dev_alloc(&h->logits, (int64_t)max_batch * h->n_live_pad));
   FMI_CHECK(dev_alloc(&h->flogits, (int64_t)max_batch * c.codebook_size));

@@ -155,7 +155,7 @@ __device__ inline bf16x8 norm_frag(uint4 xv, uint4 wv, float rstd) {
 }
 
 __global__ void rmsnorm_rows_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w, float eps,
-                                    bf16_t* __restrict__ out, int ldo, int M, int K) {
+                                    bf16_t* __restrict__ out, int ldo, int M, int K, bf16_t* __restrict__ out2) {
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int r = blockIdx.x * 4 + wave;
   if (r >= M) return;
@@ -166,13 +166,14 @@ __global__ void rmsnorm_rows_kernel(const bf16_t* __restrict__ x, int ldx, const
     uint4 wv = *reinterpret_cast<const uint4*>(w + c);
     bf16x8 o = norm_frag(xv, wv, rstd);
     *reinterpret_cast<bf16x8*>(out + (int64_t)r * ldo + c) = o;
+    if (out2) *reinterpret_cast<bf16x8*>(out2 + (int64_t)r * ldo + c) = o;
   }
 }
 
 int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf16_t* out, int ldo, int M, int K,
-                        hipStream_t s) {
+                        hipStream_t s, bf16_t* out2) {
   FMI_REQUIRE(K % 8 == 0, "rmsnorm: K %% 8");
-  hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, w, eps, out, ldo, M, K);
+  hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, w, eps, out, ldo, M, K, out2);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }

