@@ -1,16 +1,685 @@
-// placeholder until the codec lands
+// dac.hip -- host side of the codec behind the C ABI: weight registry + arena, decode / encode graphs.
+//
+// Reference call path replaced (fish_speech/models/dac/):
+//   DAC.from_indices / DAC.decode   modded_dac.py:925-946  (quantizer.decode rvq.py:352-366 + Decoder)
+//   DAC.encode                      modded_dac.py:874-923  (Encoder + quantizer.forward rvq.py:293-316)
+// Tensor names are the keys of codec.pth after weight-norm folding ("....conv.weight").
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
 #include "dac_kernels.h"
+
 using namespace fmi;
-struct fmi_dac { int dummy; };
-extern "C" {
-int64_t fmi_dac_arena_bytes(const fmi_dac_config*) { return -1; }
-int fmi_dac_create(const fmi_dac_config*, void*, int64_t, fmi_dac**) { return set_error(FMI_ESTATE, "codec not built"); }
-void fmi_dac_destroy(fmi_dac*) {}
-int fmi_dac_load_tensor(fmi_dac*, const char*, const float*, int, const int64_t*, int, void*) { return set_error(FMI_ESTATE, "codec not built"); }
-int fmi_dac_finalize_weights(fmi_dac*, void*) { return set_error(FMI_ESTATE, "codec not built"); }
-int fmi_dac_weights_ready(fmi_dac*) { return set_error(FMI_ESTATE, "codec not built"); }
-int fmi_dac_decode(fmi_dac*, int64_t*, int, int, float*, void*) { return set_error(FMI_ESTATE, "codec not built"); }
-int fmi_dac_encode(fmi_dac*, const float*, int, int, int64_t*, void*) { return set_error(FMI_ESTATE, "codec not built"); }
-int fmi_dac_frame_length(const fmi_dac*) { return 0; }
-int fmi_dac_debug_z(fmi_dac*, float**, int*, int*) { return set_error(FMI_ESTATE, "codec not built"); }
+
+namespace {
+
+enum SlotKind { K_RAW, K_CONV, K_CONVTR, K_CONV_PART };
+
+struct Slot {
+  SlotKind kind;
+  float* dst;
+  std::vector<int64_t> dims;  // expected source dims
+  int cout_pad = 0, cin_pad = 0, stride = 1, co_off = 0;
+  bool loaded = false;
+};
+
+struct Conv {
+  ConvW w;
+  int k = 1, stride = 1, dil = 1;
+  bool transposed = false;
+};
+
+struct ResUnit {
+  float *a1 = nullptr, *a2 = nullptr;
+  Conv c7, c1;
+  int dil = 1;
+};
+
+struct TfLayer {
+  float *attn_norm, *ffn_norm, *g_attn, *g_ffn;
+  Conv wqkv, wo, w13, w2;
+};
+struct Tf {
+  std::vector<TfLayer> layers;
+  float* norm = nullptr;
+  int dim = 0, ffn = 0, window = 0;
+};
+
+struct ConvNeXt {
+  float *dw_w, *dw_b, *ln_w, *ln_b, *gamma;
+  Conv pw1, pw2;
+};
+
+struct EncBlock {
+  ResUnit ru[3];
+  float* alpha;
+  Conv down;
+  bool has_tf = false;
+  Tf tf;
+};
+struct DecBlock {
+  float* alpha;
+  Conv up;
+  ResUnit ru[3];
+};
+struct VQ {
+  float *in_w, *in_b, *cb, *out_w, *out_b;
+  int n;
+};
+
+struct Buf {
+  float* p = nullptr;
+  int64_t n = 0;
+};
+
+}  // namespace
+
+struct fmi_dac {
+  fmi_dac_config cfg;
+  char* arena = nullptr;
+  int64_t arena_bytes = 0, off = 0;
+  std::map<std::string, Slot> reg;
+  bool ready = false, rope_loaded = false;
+  int head_dim = 64;
+  float eps = 1e-5f;
+  // model
+  float *first_w = nullptr, *first_b = nullptr;
+  std::vector<EncBlock> enc;
+  float* enc_alpha = nullptr;
+  Conv enc_out;
+  std::vector<Conv> down_conv, up_conv;
+  std::vector<ConvNeXt> down_cnx, up_cnx;
+  Tf pre, post;
+  VQ sem;
+  std::vector<VQ> rvq;
+  float* lut = nullptr;
+  int* lut_off = nullptr;
+  Conv dec_in;
+  std::vector<DecBlock> dec;
+  float *dec_alpha = nullptr, *final_w = nullptr, *final_b = nullptr;
+  bf16_t* rope = nullptr;
+  int rope_pos = 0;
+  // runtime
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  Buf buf[6];
+  void* staging = nullptr;
+  size_t staging_bytes = 0;
+  float* last_z = nullptr;
+  int last_zC = 0, last_zL = 0;
+};
+
+namespace {
+
+constexpr int ROPE_POSITIONS = 32768;
+
+int frame_length(const fmi_dac_config& c) {
+  int h = 1;
+  for (int i = 0; i < 4; ++i) h *= c.encoder_rates[i];
+  return h * c.downsample[0] * c.downsample[1];
 }
+
+int validate(const fmi_dac_config& c) {
+  FMI_REQUIRE(c.encoder_dim > 0 && c.decoder_dim > 0 && c.latent_dim == c.encoder_dim * 16, "latent_dim must be encoder_dim*16");
+  FMI_REQUIRE(c.latent_dim % 64 == 0, "latent_dim %% 64 (transformer head_dim 64)");
+  FMI_REQUIRE(c.codebook_dim >= 1 && c.codebook_dim <= 16, "codebook_dim in [1,16]");
+  FMI_REQUIRE(c.n_codebooks >= 1 && c.n_codebooks <= 32, "n_codebooks");
+  for (int i = 0; i < 4; ++i) FMI_REQUIRE(c.encoder_rates[i] >= 1 && c.decoder_rates[i] >= 1, "rates");
+  FMI_REQUIRE(c.decoder_dim % 16 == 0, "decoder_dim %% 16");
+  FMI_REQUIRE(c.tf_ffn > 0 && c.tf_layers >= 0 && c.tf_window > 0 && c.enc_tf_window > 0, "transformer config");
+  return FMI_OK;
+}
+
+// ---- arena bump allocation + registry.  With h->arena == nullptr only the size is computed.
+struct Builder {
+  fmi_dac* h;
+  int64_t off = 0;
+  float* take(int64_t elems, int esize = 4) {
+    float* p = h->arena ? (float*)(h->arena + off) : nullptr;
+    off = align_up(off + elems * esize, 256);
+    return p;
+  }
+  float* raw(const std::string& name, std::vector<int64_t> dims) {
+    int64_t n = 1;
+    for (auto d : dims) n *= d;
+    float* p = take(n);
+    Slot s;
+    s.kind = K_RAW; s.dst = p; s.dims = dims;
+    h->reg[name] = s;
+    return p;
+  }
+  Conv conv(const std::string& prefix, int cout, int cin, int k, int stride, int dil, bool bias, bool transposed) {
+    Conv c;
+    c.k = k; c.stride = stride; c.dil = dil; c.transposed = transposed;
+    c.w.cin = cin; c.w.cout = cout;
+    c.w.cin_pad = (int)align_up(cin, 8);
+    c.w.cout_pad = (int)align_up(cout, 32);
+    if (transposed) {
+      c.w.phases = stride;
+      c.w.taps = k / stride;
+    } else {
+      c.w.phases = 1;
+      c.w.taps = k;
+    }
+    float* wp = take((int64_t)c.w.phases * c.w.taps * c.w.cin_pad * c.w.cout_pad);
+    c.w.w = wp;
+    Slot s;
+    s.kind = transposed ? K_CONVTR : K_CONV; s.dst = wp;
+    s.dims = transposed ? std::vector<int64_t>{cin, cout, k} : std::vector<int64_t>{cout, cin, k};
+    s.cout_pad = c.w.cout_pad; s.cin_pad = c.w.cin_pad; s.stride = stride;
+    h->reg[prefix + ".weight"] = s;
+    if (bias) c.w.bias = raw(prefix + ".bias", {cout});
+    return c;
+  }
+  // linear layer (k=1, no bias) whose rows come from `parts` checkpoint tensors stacked along cout
+  Conv linear_parts(const std::vector<std::string>& names, int cout_each, int cin) {
+    Conv c;
+    const int cout = cout_each * (int)names.size();
+    c.w.cin = cin; c.w.cout = cout;
+    c.w.cin_pad = (int)align_up(cin, 8);
+    c.w.cout_pad = (int)align_up(cout, 32);
+    float* wp = take((int64_t)c.w.cin_pad * c.w.cout_pad);
+    c.w.w = wp;
+    for (size_t i = 0; i < names.size(); ++i) {
+      Slot s;
+      s.kind = K_CONV_PART; s.dst = wp; s.dims = {cout_each, cin};
+      s.cout_pad = c.w.cout_pad; s.cin_pad = c.w.cin_pad; s.co_off = (int)i * cout_each;
+      h->reg[names[i]] = s;
+    }
+    return c;
+  }
+  ResUnit res_unit(const std::string& p, int dim, int dil) {
+    ResUnit r;
+    r.dil = dil;
+    r.a1 = raw(p + ".block.0.alpha", {1, dim, 1});
+    r.c7 = conv(p + ".block.1.conv", dim, dim, 7, 1, dil, true, false);
+    r.a2 = raw(p + ".block.2.alpha", {1, dim, 1});
+    r.c1 = conv(p + ".block.3.conv", dim, dim, 1, 1, 1, true, false);
+    return r;
+  }
+  Tf transformer(const std::string& p, int dim, int n_layer, int ffn, int window) {
+    Tf t;
+    t.dim = dim; t.ffn = ffn; t.window = window;
+    for (int i = 0; i < n_layer; ++i) {
+      const std::string l = p + ".layers." + std::to_string(i);
+      TfLayer L;
+      L.wqkv = linear_parts({l + ".attention.wqkv.weight"}, 3 * dim, dim);
+      L.wo = linear_parts({l + ".attention.wo.weight"}, dim, dim);
+      L.w13 = linear_parts({l + ".feed_forward.w1.weight", l + ".feed_forward.w3.weight"}, ffn, dim);
+      L.w2 = linear_parts({l + ".feed_forward.w2.weight"}, dim, ffn);
+      L.ffn_norm = raw(l + ".ffn_norm.weight", {dim});
+      L.attn_norm = raw(l + ".attention_norm.weight", {dim});
+      L.g_attn = raw(l + ".attention_layer_scale.gamma", {dim});
+      L.g_ffn = raw(l + ".ffn_layer_scale.gamma", {dim});
+      t.layers.push_back(L);
+    }
+    t.norm = raw(p + ".norm.weight", {dim});
+    return t;
+  }
+  ConvNeXt convnext(const std::string& p, int L) {
+    ConvNeXt c;
+    c.gamma = raw(p + ".gamma", {L});
+    c.dw_w = raw(p + ".dwconv.conv.weight", {L, 1, 7});
+    c.dw_b = raw(p + ".dwconv.conv.bias", {L});
+    c.ln_w = raw(p + ".norm.weight", {L});
+    c.ln_b = raw(p + ".norm.bias", {L});
+    c.pw1 = linear_parts({p + ".pwconv1.weight"}, 4 * L, L);
+    c.pw1.w.bias = raw(p + ".pwconv1.bias", {4 * L});
+    c.pw2 = linear_parts({p + ".pwconv2.weight"}, L, 4 * L);
+    c.pw2.w.bias = raw(p + ".pwconv2.bias", {L});
+    return c;
+  }
+  VQ vq(const std::string& p, int L, int d, int n) {
+    VQ v;
+    v.n = n;
+    v.in_b = raw(p + ".in_proj.bias", {d});
+    v.in_w = raw(p + ".in_proj.weight", {d, L, 1});
+    v.out_b = raw(p + ".out_proj.bias", {L});
+    v.out_w = raw(p + ".out_proj.weight", {L, d, 1});
+    v.cb = raw(p + ".codebook.weight", {n, d});
+    return v;
+  }
+};
+
+int64_t build(fmi_dac* h) {
+  const fmi_dac_config& c = h->cfg;
+  Builder b{h};
+  h->reg.clear();
+  h->enc.clear(); h->dec.clear(); h->rvq.clear();
+  h->down_conv.clear(); h->up_conv.clear(); h->down_cnx.clear(); h->up_cnx.clear();
+  const int L = c.latent_dim;
+  // encoder (modded_dac.py:670-709)
+  int d = c.encoder_dim;
+  h->first_b = b.raw("encoder.block.0.conv.bias", {d});
+  h->first_w = b.raw("encoder.block.0.conv.weight", {d, 1, 7});
+  for (int bi = 0; bi < 4; ++bi) {
+    d *= 2;
+    const std::string p = "encoder.block." + std::to_string(bi + 1);
+    EncBlock e;
+    const int dils[3] = {1, 3, 9};
+    for (int r = 0; r < 3; ++r) e.ru[r] = b.res_unit(p + ".block." + std::to_string(r), d / 2, dils[r]);
+    e.alpha = b.raw(p + ".block.3.alpha", {1, d / 2, 1});
+    const int s = c.encoder_rates[bi];
+    e.down = b.conv(p + ".block.4.conv", d, d / 2, 2 * s, s, 1, true, false);
+    if (bi == 3 && c.enc_tf_layers > 0) {
+      e.has_tf = true;
+      e.tf = b.transformer(p + ".block.5", d, c.enc_tf_layers, d * 3, c.enc_tf_window);
+    }
+    h->enc.push_back(e);
+  }
+  h->enc_alpha = b.raw("encoder.block.5.alpha", {1, d, 1});
+  h->enc_out = b.conv("encoder.block.6.conv", L, d, 3, 1, 1, true, false);
+  // quantizer (rvq.py:204-291)
+  h->sem = b.vq("quantizer.semantic_quantizer.quantizers.0", L, c.codebook_dim, c.semantic_codebook_size);
+  for (int i = 0; i < c.n_codebooks; ++i)
+    h->rvq.push_back(b.vq("quantizer.quantizer.quantizers." + std::to_string(i), L, c.codebook_dim, c.codebook_size));
+  for (int i = 0; i < 2; ++i) {
+    const std::string p = "quantizer.downsample." + std::to_string(i);
+    h->down_conv.push_back(b.conv(p + ".0.conv", L, L, c.downsample[i], c.downsample[i], 1, true, false));
+    h->down_cnx.push_back(b.convnext(p + ".1", L));
+  }
+  for (int i = 0; i < 2; ++i) {
+    const std::string p = "quantizer.upsample." + std::to_string(i);
+    const int f = c.downsample[1 - i];
+    h->up_conv.push_back(b.conv(p + ".0.conv", L, L, f, f, 1, true, true));
+    h->up_cnx.push_back(b.convnext(p + ".1", L));
+  }
+  h->pre = b.transformer("quantizer.pre_module", L, c.tf_layers, c.tf_ffn, c.tf_window);
+  h->post = b.transformer("quantizer.post_module", L, c.tf_layers, c.tf_ffn, c.tf_window);
+  const int64_t lut_rows = c.semantic_codebook_size + (int64_t)c.n_codebooks * c.codebook_size;
+  h->lut = b.take(lut_rows * L);
+  h->lut_off = (int*)b.take(c.n_codebooks + 2, 4);
+  // decoder (modded_dac.py:760-801)
+  h->dec_in = b.conv("decoder.model.0.conv", c.decoder_dim, L, 7, 1, 1, true, false);
+  for (int i = 0; i < 4; ++i) {
+    const int cin = c.decoder_dim >> i, cout = c.decoder_dim >> (i + 1);
+    const std::string p = "decoder.model." + std::to_string(i + 1);
+    DecBlock db;
+    db.alpha = b.raw(p + ".block.0.alpha", {1, cin, 1});
+    const int s = c.decoder_rates[i];
+    db.up = b.conv(p + ".block.1.conv", cout, cin, 2 * s, s, 1, true, true);
+    const int dils[3] = {1, 3, 9};
+    for (int r = 0; r < 3; ++r) db.ru[r] = b.res_unit(p + ".block." + std::to_string(2 + r), cout, dils[r]);
+    h->dec.push_back(db);
+  }
+  const int cl = c.decoder_dim >> 4;
+  h->dec_alpha = b.raw("decoder.model.5.alpha", {1, cl, 1});
+  h->final_b = b.raw("decoder.model.6.conv.bias", {1});
+  h->final_w = b.raw("decoder.model.6.conv.weight", {1, cl, 7});
+  h->rope = (bf16_t*)b.take((int64_t)ROPE_POSITIONS * h->head_dim, 2);
+  h->rope_pos = ROPE_POSITIONS;
+  return b.off;
+}
+
+int ensure_staging(fmi_dac* h, size_t bytes) {
+  if (h->staging_bytes >= bytes) return FMI_OK;
+  if (h->staging) hipFree(h->staging);
+  h->staging = nullptr;
+  h->staging_bytes = 0;
+  FMI_CHECK_HIP(hipMalloc(&h->staging, bytes));
+  h->staging_bytes = bytes;
+  return FMI_OK;
+}
+
+int ensure_buf(fmi_dac* h, int i, int64_t n) {
+  if (h->buf[i].n >= n) return FMI_OK;
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  if (h->buf[i].p) hipFree(h->buf[i].p);
+  h->buf[i].p = nullptr;
+  h->buf[i].n = 0;
+  FMI_CHECK_HIP(hipMalloc((void**)&h->buf[i].p, (size_t)n * 4));
+  h->buf[i].n = n;
+  return FMI_OK;
+}
+
+int sync_in(fmi_dac* h, void* us) {
+  FMI_CHECK_HIP(hipEventRecord(h->ev_in, (hipStream_t)us));
+  FMI_CHECK_HIP(hipStreamWaitEvent(h->stream, h->ev_in, 0));
+  return FMI_OK;
+}
+int sync_out(fmi_dac* h, void* us) {
+  FMI_CHECK_HIP(hipEventRecord(h->ev_out, h->stream));
+  FMI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)us, h->ev_out, 0));
+  return FMI_OK;
+}
+
+// ---- layer runners (channel-major [B][C][L])
+
+int run_conv(fmi_dac* h, const Conv& c, const float* x, float* out, int B, int lin, int* lout_p, const float* snake,
+             const float* res, const float* gamma, int act) {
+  ConvArgs a{};
+  a.w = c.w; a.x = x; a.out = out; a.snake_alpha = snake; a.res = res; a.gamma = gamma; a.B = B; a.lin = lin;
+  a.act = act;
+  int lout;
+  if (c.transposed) {  // CausalTransConvNet: (lin-1)*s + k - (k - s) = lin * s
+    lout = lin * c.stride;
+    a.x_stride = 1; a.tap_step = -1; a.tap_base = 0; a.out_stride = c.stride;
+  } else {             // CausalConvNet: left pad k_eff - stride, output ceil(lin / stride)
+    const int k_eff = (c.k - 1) * c.dil + 1;
+    lout = cdiv(lin, c.stride);
+    a.x_stride = c.stride; a.tap_step = c.dil; a.tap_base = -(k_eff - c.stride); a.out_stride = 1;
+  }
+  a.lout = lout;
+  if (lout_p) *lout_p = lout;
+  return launch_conv(a, h->stream);
+}
+
+// ResidualUnit in place on x, y = scratch of the same size
+int run_res_unit(fmi_dac* h, const ResUnit& r, float* x, float* y, int B, int L) {
+  FMI_CHECK(run_conv(h, r.c7, x, y, B, L, nullptr, r.a1, nullptr, nullptr, ACT_NONE));
+  return run_conv(h, r.c1, y, x, B, L, nullptr, r.a2, x, nullptr, ACT_NONE);
+}
+
+// WindowLimitedTransformer on x [B][dim][T]; result written to out (may alias x)
+int run_transformer(fmi_dac* h, const Tf& t, float* x, float* out, int B, int T) {
+  const int C = t.dim, F = t.ffn;
+  FMI_REQUIRE(T <= h->rope_pos, "sequence of %d frames exceeds the RoPE table (%d)", T, h->rope_pos);
+  FMI_CHECK(ensure_buf(h, 2, (int64_t)B * C * T));       // norm / attention output
+  FMI_CHECK(ensure_buf(h, 3, (int64_t)B * 3 * C * T));   // qkv
+  FMI_CHECK(ensure_buf(h, 4, (int64_t)B * 2 * F * T));   // w1|w3 output
+  FMI_CHECK(ensure_buf(h, 5, (int64_t)B * F * T));       // activation
+  float *nb = h->buf[2].p, *qkv = h->buf[3].p, *ab = h->buf[4].p, *act = h->buf[5].p;
+  hipStream_t s = h->stream;
+  for (const TfLayer& L : t.layers) {
+    FMI_CHECK(launch_rmsnorm_cols(x, L.attn_norm, h->eps, nb, B, C, T, s));
+    FMI_CHECK(run_conv(h, L.wqkv, nb, qkv, B, T, nullptr, nullptr, nullptr, nullptr, ACT_NONE));
+    FMI_CHECK(launch_rope_cols(qkv, h->rope, B, C, T, h->head_dim, s));
+    FMI_CHECK(launch_window_attn(qkv, nb, B, C, T, h->head_dim, t.window, s));
+    FMI_CHECK(run_conv(h, L.wo, nb, x, B, T, nullptr, nullptr, x, L.g_attn, ACT_NONE));
+    FMI_CHECK(launch_rmsnorm_cols(x, L.ffn_norm, h->eps, nb, B, C, T, s));
+    FMI_CHECK(run_conv(h, L.w13, nb, ab, B, T, nullptr, nullptr, nullptr, nullptr, ACT_NONE));
+    FMI_CHECK(launch_silu_mul(ab, act, B, F, T, s));
+    FMI_CHECK(run_conv(h, L.w2, act, x, B, T, nullptr, nullptr, x, L.g_ffn, ACT_NONE));
+  }
+  return launch_rmsnorm_cols(x, t.norm, h->eps, out, B, C, T, s);
+}
+
+// ConvNeXtBlock in place on x [B][L][T]
+int run_convnext(fmi_dac* h, const ConvNeXt& c, float* x, int B, int C, int T) {
+  FMI_CHECK(ensure_buf(h, 2, (int64_t)B * C * T));
+  FMI_CHECK(ensure_buf(h, 3, (int64_t)B * C * T));
+  FMI_CHECK(ensure_buf(h, 4, (int64_t)B * 4 * C * T));
+  float *y = h->buf[2].p, *n = h->buf[3].p, *hid = h->buf[4].p;
+  hipStream_t s = h->stream;
+  FMI_CHECK(launch_dwconv7(x, c.dw_w, c.dw_b, y, B, C, T, s));
+  FMI_CHECK(launch_layernorm_cols(y, c.ln_w, c.ln_b, 1e-6f, n, B, C, T, s));
+  FMI_CHECK(run_conv(h, c.pw1, n, hid, B, T, nullptr, nullptr, nullptr, nullptr, ACT_GELU));
+  return run_conv(h, c.pw2, hid, x, B, T, nullptr, nullptr, x, c.gamma, ACT_NONE);
+}
+
+int64_t decode_peak_elems(const fmi_dac_config& c, int T) {
+  int64_t peak = (int64_t)c.latent_dim * 4 * T;
+  int64_t L = 4 * (int64_t)T;
+  peak = std::max(peak, (int64_t)c.decoder_dim * L);
+  for (int i = 0; i < 4; ++i) {
+    L *= c.decoder_rates[i];
+    peak = std::max(peak, (int64_t)(c.decoder_dim >> (i + 1)) * L);
+  }
+  return peak;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t fmi_dac_arena_bytes(const fmi_dac_config* cfg) {
+  if (!cfg || validate(*cfg) != FMI_OK) return -1;
+  fmi_dac tmp;
+  tmp.cfg = *cfg;
+  return build(&tmp);
+}
+
+int fmi_dac_create(const fmi_dac_config* cfg, void* arena_dev, int64_t arena_bytes, fmi_dac** out) {
+  FMI_REQUIRE(cfg && arena_dev && out, "null argument");
+  FMI_CHECK(validate(*cfg));
+  fmi_dac* h = new fmi_dac();
+  h->cfg = *cfg;
+  h->arena = (char*)arena_dev;
+  h->arena_bytes = arena_bytes;
+  const int64_t need = build(h);
+  if (arena_bytes < need) {
+    delete h;
+    return set_error(FMI_EINVAL, "arena too small: %lld < %lld", (long long)arena_bytes, (long long)need);
+  }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
+    delete h;
+    return set_error(FMI_EHIP, "stream/event creation failed (no GPU?)");
+  }
+  hipMemsetAsync(h->arena, 0, (size_t)need, h->stream);  // padded weight tiles must be zero
+  hipStreamSynchronize(h->stream);
+  *out = h;
+  return FMI_OK;
+}
+
+void fmi_dac_destroy(fmi_dac* h) {
+  if (!h) return;
+  hipStreamSynchronize(h->stream);
+  for (auto& b : h->buf)
+    if (b.p) hipFree(b.p);
+  if (h->staging) hipFree(h->staging);
+  hipEventDestroy(h->ev_in);
+  hipEventDestroy(h->ev_out);
+  hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int fmi_dac_frame_length(const fmi_dac* h) { return h ? frame_length(h->cfg) : 0; }
+
+int fmi_dac_load_tensor(fmi_dac* h, const char* name_c, const float* src, int ndim, const int64_t* dims,
+                        int src_is_device, void* stream) {
+  FMI_REQUIRE(h && name_c && src && dims && ndim >= 1 && ndim <= 3, "bad argument");
+  const std::string name(name_c);
+  if (name == "rope_table") {  // bf16 (positions, head_dim) table built by the host with torch
+    FMI_REQUIRE(ndim == 2 && dims[1] == h->head_dim && dims[0] <= h->rope_pos, "rope_table shape");
+    FMI_CHECK(sync_in(h, stream));
+    FMI_CHECK_HIP(hipMemcpyAsync(h->rope, src, (size_t)dims[0] * dims[1] * 2,
+                                 src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+    h->rope_loaded = true;
+    h->rope_pos = (int)dims[0];
+    return sync_out(h, stream);
+  }
+  auto it = h->reg.find(name);
+  if (it == h->reg.end()) return set_error(FMI_EINVAL, "unknown codec tensor '%s'", name.c_str());
+  Slot& s = it->second;
+  int64_t n = 1, ne = 1;
+  for (int i = 0; i < ndim; ++i) n *= dims[i];
+  for (auto d : s.dims) ne *= d;
+  bool ok = n == ne;
+  if (ok && s.kind != K_RAW) {  // leading dims must match exactly for re-tiled tensors
+    std::vector<int64_t> got(dims, dims + ndim);
+    while (got.size() < s.dims.size()) got.push_back(1);
+    ok = got == s.dims;
+  }
+  if (!ok) return set_error(FMI_EINVAL, "%s: unexpected shape (%lld elements, expected %lld)", name.c_str(), (long long)n, (long long)ne);
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t st = h->stream;
+  const float* dsrc = src;
+  if (!src_is_device) {
+    FMI_CHECK(ensure_staging(h, (size_t)n * 4));
+    FMI_CHECK_HIP(hipMemcpyAsync(h->staging, src, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    dsrc = (const float*)h->staging;
+  }
+  int rc = FMI_OK;
+  switch (s.kind) {
+    case K_RAW:
+      FMI_CHECK_HIP(hipMemcpyAsync(s.dst, dsrc, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+      break;
+    case K_CONV:
+      rc = launch_pack_conv(dsrc, s.dst, (int)s.dims[0], (int)s.dims[1], (int)s.dims[2], s.cin_pad, s.cout_pad, st);
+      break;
+    case K_CONVTR:
+      rc = launch_pack_convtr(dsrc, s.dst, (int)s.dims[0], (int)s.dims[1], (int)s.dims[2], s.stride, s.cin_pad,
+                              s.cout_pad, st);
+      break;
+    case K_CONV_PART:  // rows [co_off, co_off+cout) of a stacked k=1 weight; padding stays zero (arena memset)
+      rc = launch_pack_conv_part(dsrc, s.dst, (int)s.dims[0], (int)s.dims[1], s.cout_pad, s.co_off, st);
+      break;
+  }
+  FMI_CHECK(rc);
+  FMI_CHECK_HIP(hipStreamSynchronize(st));
+  s.loaded = true;
+  return sync_out(h, stream);
+}
+
+int fmi_dac_finalize_weights(fmi_dac* h, void* stream) {
+  FMI_REQUIRE(h, "null handle");
+  for (auto& kv : h->reg)
+    if (!kv.second.loaded) return set_error(FMI_ESTATE, "codec tensor '%s' was never loaded", kv.first.c_str());
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  const fmi_dac_config& c = h->cfg;
+  const int L = c.latent_dim;
+  // decode tables: out_proj of every code (from_codes = sum of table rows)
+  std::vector<int> off(c.n_codebooks + 2);
+  off[0] = 0;
+  off[1] = c.semantic_codebook_size;
+  for (int i = 1; i <= c.n_codebooks; ++i) off[i + 1] = off[i] + c.codebook_size;
+  FMI_CHECK_HIP(hipMemcpyAsync(h->lut_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK(launch_build_lut(h->sem.cb, h->sem.out_w, h->sem.out_b, h->lut, h->sem.n, c.codebook_dim, L, s));
+  for (int i = 0; i < c.n_codebooks; ++i)
+    FMI_CHECK(launch_build_lut(h->rvq[i].cb, h->rvq[i].out_w, h->rvq[i].out_b, h->lut + (int64_t)off[i + 1] * L,
+                               h->rvq[i].n, c.codebook_dim, L, s));
+  if (!h->rope_loaded) {  // fallback: host cosf/sinf (the shim normally supplies torch's table)
+    std::vector<bf16_t> tab((size_t)h->rope_pos * h->head_dim);
+    const int hd = h->head_dim;
+    for (int k = 0; k < hd / 2; ++k) {
+      const float freq = 1.0f / powf(10000.0f, (float)(2 * k) / (float)hd);
+      for (int p = 0; p < h->rope_pos; ++p) {
+        tab[((size_t)p * (hd / 2) + k) * 2] = f2bf(cosf((float)p * freq));
+        tab[((size_t)p * (hd / 2) + k) * 2 + 1] = f2bf(sinf((float)p * freq));
+      }
+    }
+    FMI_CHECK_HIP(hipMemcpyAsync(h->rope, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, s));
+  }
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  h->ready = true;
+  return sync_out(h, stream);
+}
+
+int fmi_dac_weights_ready(fmi_dac* h) {
+  FMI_REQUIRE(h, "null handle");
+  h->ready = true;
+  return FMI_OK;
+}
+
+int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_out_dev, void* stream) {
+  FMI_REQUIRE(h && indices_dev && audio_out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "codec weights not ready");
+  FMI_REQUIRE(B >= 1 && T >= 1, "empty input");
+  const fmi_dac_config& c = h->cfg;
+  const int L0 = c.latent_dim;
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  const int64_t peak = (int64_t)B * decode_peak_elems(c, T);
+  FMI_CHECK(ensure_buf(h, 0, peak));
+  FMI_CHECK(ensure_buf(h, 1, peak));
+  float *X = h->buf[0].p, *Y = h->buf[1].p;
+  // quantizer.decode (rvq.py:352-366)
+  FMI_CHECK(launch_clamp_indices(indices_dev, B, c.n_codebooks + 1, T, c.semantic_codebook_size, c.codebook_size, s));
+  FMI_CHECK(launch_lut_decode(indices_dev, h->lut, h->lut_off, c.n_codebooks, c.semantic_codebook_size, c.codebook_size,
+                              X, B, L0, T, s));
+  FMI_CHECK(run_transformer(h, h->post, X, X, B, T));
+  int len = T;
+  for (int i = 0; i < 2; ++i) {
+    int l2;
+    FMI_CHECK(run_conv(h, h->up_conv[i], X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
+    std::swap(X, Y);
+    len = l2;
+    FMI_CHECK(run_convnext(h, h->up_cnx[i], X, B, L0, len));
+  }
+  h->last_z = X; h->last_zC = L0; h->last_zL = len;
+  // the debug tap must survive the decoder: keep z in buffer 2..5? it is small -> copy to buf[5]
+  FMI_CHECK(ensure_buf(h, 5, (int64_t)B * L0 * len));
+  FMI_CHECK_HIP(hipMemcpyAsync(h->buf[5].p, X, (size_t)B * L0 * len * 4, hipMemcpyDeviceToDevice, s));
+  h->last_z = h->buf[5].p;
+  // Decoder (modded_dac.py:760-801)
+  int l2;
+  FMI_CHECK(run_conv(h, h->dec_in, X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
+  std::swap(X, Y);
+  for (const DecBlock& db : h->dec) {
+    FMI_CHECK(run_conv(h, db.up, X, Y, B, len, &l2, db.alpha, nullptr, nullptr, ACT_NONE));
+    std::swap(X, Y);
+    len = l2;
+    for (int r = 0; r < 3; ++r) FMI_CHECK(run_res_unit(h, db.ru[r], X, Y, B, len));
+  }
+  FMI_CHECK(launch_final_conv_tanh(X, h->dec_alpha, h->final_w, h->final_b, audio_out_dev, B, c.decoder_dim >> 4, len, s));
+  return sync_out(h, stream);
+}
+
+int fmi_dac_debug_z(fmi_dac* h, float** z_dev, int* C, int* L) {
+  FMI_REQUIRE(h && h->last_z, "no decode has run");
+  if (z_dev) *z_dev = h->last_z;
+  if (C) *C = h->last_zC;
+  if (L) *L = h->last_zL;
+  return FMI_OK;
+}
+
+int fmi_dac_encode(fmi_dac* h, const float* audio_dev, int B, int N, int64_t* indices_out_dev, void* stream) {
+  FMI_REQUIRE(h && audio_dev && indices_out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "codec weights not ready");
+  const fmi_dac_config& c = h->cfg;
+  const int fl = frame_length(c);
+  FMI_REQUIRE(B >= 1 && N >= fl && N % fl == 0, "audio length %d must be a positive multiple of frame_length %d", N, fl);
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  // peak activation: the block-1 residual units run at full rate on encoder_dim channels
+  int64_t peak = (int64_t)c.encoder_dim * N;
+  {
+    int d = c.encoder_dim;
+    int64_t len = N;
+    for (int i = 0; i < 4; ++i) {
+      d *= 2;
+      peak = std::max(peak, (int64_t)(d / 2) * len);
+      len /= c.encoder_rates[i];
+      peak = std::max(peak, (int64_t)d * len);
+    }
+  }
+  FMI_CHECK(ensure_buf(h, 0, (int64_t)B * peak));
+  FMI_CHECK(ensure_buf(h, 1, (int64_t)B * peak));
+  float *X = h->buf[0].p, *Y = h->buf[1].p;
+  int len = N;
+  FMI_CHECK(launch_first_conv(audio_dev, h->first_w, h->first_b, X, B, c.encoder_dim, len, s));
+  int d = c.encoder_dim;
+  for (const EncBlock& e : h->enc) {
+    d *= 2;
+    for (int r = 0; r < 3; ++r) FMI_CHECK(run_res_unit(h, e.ru[r], X, Y, B, len));
+    int l2;
+    FMI_CHECK(run_conv(h, e.down, X, Y, B, len, &l2, e.alpha, nullptr, nullptr, ACT_NONE));
+    std::swap(X, Y);
+    len = l2;
+    if (e.has_tf) FMI_CHECK(run_transformer(h, e.tf, X, X, B, len));
+  }
+  FMI_CHECK(run_conv(h, h->enc_out, X, Y, B, len, nullptr, h->enc_alpha, nullptr, nullptr, ACT_NONE));
+  std::swap(X, Y);
+  // quantizer.forward up to the codes (rvq.py:293-316)
+  const int L0 = c.latent_dim;
+  for (int i = 0; i < 2; ++i) {
+    int l2;
+    FMI_CHECK(run_conv(h, h->down_conv[i], X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
+    std::swap(X, Y);
+    len = l2;
+    FMI_CHECK(run_convnext(h, h->down_cnx[i], X, B, L0, len));
+  }
+  FMI_CHECK(run_transformer(h, h->pre, X, X, B, len));
+  VqArgs v{};
+  v.residual = X; v.B = B; v.C = L0; v.T = len; v.d = c.codebook_dim; v.books = c.n_codebooks + 1;
+  v.codes = indices_out_dev;
+  auto step = [&](const VQ& q, int book) {
+    v.in_w = q.in_w; v.in_b = q.in_b; v.codebook = q.cb; v.out_w = q.out_w; v.out_b = q.out_b; v.n = q.n;
+    v.book = book;
+    return launch_vq_step(v, s);
+  };
+  FMI_CHECK(step(h->sem, 0));
+  for (int i = 0; i < c.n_codebooks; ++i) FMI_CHECK(step(h->rvq[i], i + 1));
+  return sync_out(h, stream);
+}
+
+}  // extern "C"

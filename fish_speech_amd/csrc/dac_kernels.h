@@ -1,3 +1,81 @@
-// dac_kernels.h -- launch wrappers of the codec kernels (dac_kernels.hip).
+// dac_kernels.h -- launch wrappers of the codec kernels (dac_kernels.hip).  All fp32, channel-major
+// activations [B][C][L] (time contiguous), like the reference's (B, C, T) tensors.
 #pragma once
 #include "common.h"
+
+namespace fmi {
+
+// Packed weight layout of one conv / linear / transposed conv, built at load time:
+//   w[phase][tap][ci_pad][co_pad]  (zero padded; ci_pad % 8 == 0, co_pad % 32 == 0)
+// regular conv:      phases = 1, taps = K
+// transposed (k=2s): phases = s, taps = 2   (tap m reads x[q - m], weight index j + m*s)
+// transposed (k=s):  phases = s, taps = 1
+struct ConvW {
+  const float* w = nullptr;
+  const float* bias = nullptr;  // [cout] or nullptr
+  int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0;
+  int phases = 1, taps = 1;
+};
+
+enum ConvAct { ACT_NONE = 0, ACT_GELU = 1 };
+
+struct ConvArgs {
+  ConvW w;
+  const float* x;       // [B][cin][lin]
+  float* out;           // [B][cout][lout]
+  const float* snake_alpha;  // [cin] fused Snake1d on the input, or nullptr
+  const float* res;     // [B][cout][lout] residual or nullptr
+  const float* gamma;   // [cout] scale applied before the residual add (LayerScale / ConvNeXt gamma)
+  int B, lin, lout;
+  int x_stride;         // input column step per output column (conv stride; 1 for transposed)
+  int tap_step;         // input column step per tap (dilation; -1 for transposed)
+  int tap_base;         // input column of tap 0 for output column 0 (= -(left pad); 0 for transposed)
+  int out_stride;       // output column step per computed column (1; stride for transposed)
+  int act;
+};
+// out[b][co][q*out_stride + phase] = res + gamma * act(bias + sum_ci sum_tap w[phase][tap][ci][co] *
+//                                    snake(x)[b][ci][q*x_stride + tap_base + tap*tap_step])
+int launch_conv(const ConvArgs& a, hipStream_t s);
+
+// weight re-layouts (run once at load)
+int launch_pack_conv(const float* w_src /*[cout][cin][k]*/, float* dst, int cout, int cin, int k, int cin_pad,
+                     int cout_pad, hipStream_t s);
+int launch_pack_conv_part(const float* w_src /*[cout][cin]*/, float* dst, int cout, int cin, int cout_pad, int co_off,
+                          hipStream_t s);
+int launch_pack_convtr(const float* w_src /*[cin][cout][k]*/, float* dst, int cin, int cout, int k, int stride,
+                       int cin_pad, int cout_pad, hipStream_t s);
+
+// elementwise / small kernels
+int launch_rmsnorm_cols(const float* x, const float* w, float eps, float* out, int B, int C, int L, hipStream_t s);
+int launch_layernorm_cols(const float* x, const float* w, const float* b, float eps, float* out, int B, int C, int L,
+                          hipStream_t s);
+int launch_dwconv7(const float* x, const float* w /*[C][7]*/, const float* b, float* out, int B, int C, int L,
+                   hipStream_t s);
+int launch_silu_mul(const float* ab /*[B][2F][L]*/, float* out /*[B][F][L]*/, int B, int F, int L, hipStream_t s);
+int launch_rope_cols(float* qkv /*[B][3C][L]*/, const bf16_t* table /*[L][hd/2][2]*/, int B, int C, int L, int hd,
+                     hipStream_t s);
+int launch_window_attn(const float* qkv /*[B][3C][L]*/, float* out /*[B][C][L]*/, int B, int C, int L, int hd,
+                       int window, hipStream_t s);
+int launch_lut_decode(const int64_t* idx /*[B][1+n][T]*/, const float* tables, const int* table_rows_off,
+                      int n_books, int sem_size, int cb_size, float* out /*[B][C][T]*/, int B, int C, int T,
+                      hipStream_t s);
+int launch_clamp_indices(int64_t* idx, int B, int n_books1, int T, int sem_size, int cb_size, hipStream_t s);
+int launch_build_lut(const float* codebook /*[n][d]*/, const float* w /*[C][d]*/, const float* bias, float* table,
+                     int n, int d, int C, hipStream_t s);
+int launch_final_conv_tanh(const float* x /*[B][C][L]*/, const float* alpha, const float* w /*[C][7]*/,
+                           const float* bias, float* out /*[B][1][L]*/, int B, int C, int L, hipStream_t s);
+int launch_first_conv(const float* x /*[B][1][L]*/, const float* w /*[C][7]*/, const float* bias, float* out,
+                      int B, int C, int L, hipStream_t s);
+struct VqArgs {
+  float* residual;        // [B][C][T], updated in place (residual -= z_q_i)
+  const float* in_w;      // [d][C]
+  const float* in_b;      // [d]
+  const float* codebook;  // [n][d]
+  const float* out_w;     // [C][d]
+  const float* out_b;     // [C]
+  int64_t* codes;         // [B][books][T], this call writes book `book`
+  int B, C, T, d, n, book, books;
+};
+int launch_vq_step(const VqArgs& a, hipStream_t s);
+
+}  // namespace fmi

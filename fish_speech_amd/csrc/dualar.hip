@@ -244,9 +244,14 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
   a.rope = h->rope; a.row_slot = row_slot; a.row_pos = row_pos; a.block_table = h->st.block_table;
   a.slot_pos = h->st.pos; a.max_pages = h->max_pages; a.rows = rows; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
   a.eps = h->cfg.norm_eps;
-  FMI_CHECK(launch_attn_prep(a, s));
-  FMI_CHECK(launch_attn(a, s));
-  h->launches += 2;
+  if (row_pos == nullptr) {  // decode: one row per slot -> fused prep + attention
+    FMI_CHECK(launch_attn_decode_fused(a, s));
+    h->launches += 1;
+  } else {
+    FMI_CHECK(launch_attn_prep(a, s));
+    FMI_CHECK(launch_attn(a, s));
+    h->launches += 2;
+  }
   FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s));
   FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s));
   FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.ffn, EPI_RESIDUAL, s));

@@ -85,6 +85,7 @@ struct AttnArgs {
 };
 int launch_attn_prep(const AttnArgs& a, hipStream_t s);
 int launch_attn(const AttnArgs& a, hipStream_t s);
+int launch_attn_decode_fused(const AttnArgs& a, hipStream_t s);  // one row per slot only
 
 struct FastAttnArgs {
   const bf16_t* qkv;   // [B][(H+2KVH)*D]

@@ -83,20 +83,35 @@ int launch_rope_table(bf16_t*, int, int, float, hipStream_t) { return FMI_OK; }
 // =====================================================================================
 
 __global__ void embed_kernel(EmbedArgs a) {
-  int r = blockIdx.x;
+  const int r = blockIdx.x;
   const int32_t* tok = a.row_slot ? a.tokens + (int64_t)a.row_slot[r] * (a.ncb + 1)
                                   : a.tokens + (int64_t)r * (a.ncb + 1);
-  int t0 = tok[0];
-  bool sem = (t0 >= a.sem_begin) && (t0 <= a.sem_end);
+  const int t0 = tok[0];
+  const bool sem = (t0 >= a.sem_begin) && (t0 <= a.sem_end);
   const float inv = sqrtf((float)(a.ncb + 1));  // x / math.sqrt(ncb+1), divisor rounded to fp32
-  for (int d = threadIdx.x; d < a.dim; d += blockDim.x) {
-    // torch.stack(embeds).sum(dim=1) on bf16: fp32 accumulation, one rounding
-    float vq = 0.f;
-    for (int i = 0; i < a.ncb; ++i) vq += bf2f(a.cb_emb[(int64_t)(tok[i + 1] + i * a.cbs) * a.dim + d]);
-    float vqr = sem ? rbf(vq) : 0.f;
-    float x = rbf(bf2f(a.emb[(int64_t)t0 * a.dim + d]) + vqr);
-    if (a.scale && sem) x = rbf(x / inv);
-    a.out[(int64_t)r * a.dim + d] = f2bf(x);
+  for (int d = threadIdx.x * 8; d < a.dim; d += blockDim.x * 8) {
+    // torch.stack(embeds).sum(dim=1) on bf16: fp32 accumulation in codebook order, one rounding
+    float vq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vq[j] = 0.f;
+    if (sem) {
+      for (int i = 0; i < a.ncb; ++i) {
+        uint4 v = *reinterpret_cast<const uint4*>(a.cb_emb + (int64_t)(tok[i + 1] + i * a.cbs) * a.dim + d);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vq[j] += bf2f(e[j]);
+      }
+    }
+    uint4 ev = *reinterpret_cast<const uint4*>(a.emb + (int64_t)t0 * a.dim + d);
+    const bf16_t* ee = reinterpret_cast<const bf16_t*>(&ev);
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = rbf(bf2f(ee[j]) + (sem ? rbf(vq[j]) : 0.f));
+      if (a.scale && sem) x = rbf(x / inv);
+      o[j] = f2bf(x);
+    }
+    *reinterpret_cast<uint4*>(a.out + (int64_t)r * a.dim + d) = *reinterpret_cast<uint4*>(o);
   }
 }
 
@@ -202,6 +217,20 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
   const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
 
   const int kbeg = (int)((int64_t)wave * KT / WAVES), kend = (int)((int64_t)(wave + 1) * KT / WAVES);
+  const u32x4* wrow[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) wrow[t] = wp + ((int64_t)(tile0 + t) * KT) * 64 + lane;
+
+  // the first chunk of weight tiles is issued BEFORE the RMSNorm prologue so that HBM latency overlaps
+  // the row statistics
+  u32x4 wa[TILES][UNR];
+  const int nfull = (kend - kbeg) / UNR;
+  if (nfull > 0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) wa[t][u] = __builtin_nontemporal_load(wrow[t] + (int64_t)(kbeg + u) * 64);
+  }
 
   float rstd = 0.f;
   if (NORM) {
@@ -221,16 +250,10 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 #pragma unroll
   for (int t = 0; t < TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int kt = kbeg;
-  for (; kt + UNR <= kend; kt += UNR) {
-    u32x4 wv[TILES][UNR];
-    uint4 xv[UNR];
-    uint4 nv[UNR];
+  auto compute_chunk = [&](u32x4 (&wv)[TILES][UNR], int kt) {
+    uint4 xv[UNR], nv[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-      for (int t = 0; t < TILES; ++t)
-        wv[t][u] = __builtin_nontemporal_load(wp + ((int64_t)(tile0 + t) * KT + kt + u) * 64 + lane);
       xv[u] = bvalid ? *reinterpret_cast<const uint4*>(xrow + (kt + u) * 32) : make_uint4(0, 0, 0, 0);
       if (NORM) nv[u] = *reinterpret_cast<const uint4*>(nrow + (kt + u) * 32);
     }
@@ -243,6 +266,19 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
       for (int t = 0; t < TILES; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[t][u]), xb, acc[t], 0, 0, 0);
     }
+  };
+  auto load_chunk = [&](u32x4 (&wv)[TILES][UNR], int kt) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) wv[t][u] = __builtin_nontemporal_load(wrow[t] + (int64_t)(kt + u) * 64);
+  };
+
+  int kt = kbeg;
+  for (int c = 0; c < nfull; ++c) {
+    compute_chunk(wa, kt);
+    kt += UNR;
+    if (c + 1 < nfull) load_chunk(wa, kt);
   }
   for (; kt < kend; ++kt) {
     uint4 xv = bvalid ? *reinterpret_cast<const uint4*>(xrow + kt * 32) : make_uint4(0, 0, 0, 0);
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 wv = __builtin_nontemporal_load(wp + ((int64_t)(tile0 + t) * KT + kt) * 64 + lane);
+      u32x4 wv = __builtin_nontemporal_load(wrow[t] + (int64_t)kt * 64);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[t], 0, 0, 0);
     }
   }
@@ -426,55 +462,51 @@ int launch_linear_tiled(const LinearArgs& a, hipStream_t s) {
 // attention: prep (q/k head norm + RoPE + paged KV write), then attention over the cache
 // =====================================================================================
 
-// one wave per head; lane p owns the RoPE pair (2p, 2p+1)
+// one wave per (row, head); lane p owns the RoPE pair (2p, 2p+1).  grid (rows, ceil(heads/4)).
 __global__ __launch_bounds__(256) void attn_prep_kernel(AttnArgs a) {
   const int r = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = a.row_slot[r];
-  const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
   const int D = a.D, H = a.H, KVH = a.KVH;
   const int total = H + 2 * KVH;
+  const int h = blockIdx.y * 4 + wave;
+  if (h >= total) return;
+  const int slot = a.row_slot[r];
+  const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
   const bf16_t* src = a.qkv + (int64_t)r * total * D;
-  const int page = a.block_table[(int64_t)slot * a.max_pages + pos / KV_PAGE];
-  const int off = pos % KV_PAGE;
-  for (int h = wave; h < total; h += 4) {
-    for (int p = lane; p < D / 2; p += 64) {
-      uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
-      float x0 = bf2f((bf16_t)(raw & 0xffff)), x1 = bf2f((bf16_t)(raw >> 16));
-      bf16_t o0, o1;
-      if (h >= H + KVH) {  // value head: plain copy
-        o0 = (bf16_t)(raw & 0xffff);
-        o1 = (bf16_t)(raw >> 16);
-      } else {
-        const bf16_t* nw = (h < H) ? a.qnw : a.knw;
-        float y0 = x0, y1 = x1;
-        if (nw) {  // torch.nn.RMSNorm: fp32 normalise * weight, one cast (llama.py:862-864)
-          // NOTE: D/2 <= 64 so one pass of the loop covers the head; partial waves reduce zeros
-          float ss = wave_sum(x0 * x0 + x1 * x1);
-          float rstd = rsqrtf(ss / (float)D + a.eps);
-          y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(nw[2 * p])));
-          y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(nw[2 * p + 1])));
-        }
-        uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
-        float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
-        // llama.py:1026-1038, separate fp32 mul / sub / add (no fused multiply-add)
-        o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
-        o1 = f2bf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
-      }
-      uint32_t packed = (uint32_t)o0 | ((uint32_t)o1 << 16);
-      if (h < H) {
-        *reinterpret_cast<uint32_t*>(a.q + ((int64_t)r * H + h) * D + 2 * p) = packed;
-      } else {
-        const int kh = (h < H + KVH) ? h - H : h - H - KVH;
-        bf16_t* pool = (h < H + KVH) ? a.kpool : a.vpool;
-        *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kh) * KV_PAGE + off) * D + 2 * p) = packed;
-      }
+  const bool act = lane < D / 2;
+  const int p = act ? lane : 0;
+  uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+  float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
+  bf16_t o0 = (bf16_t)(raw & 0xffff), o1 = (bf16_t)(raw >> 16);
+  if (h < H + KVH) {
+    const bf16_t* nw = (h < H) ? a.qnw : a.knw;
+    float y0 = x0, y1 = x1;
+    if (nw) {  // torch.nn.RMSNorm: fp32 normalise * weight, one cast (llama.py:862-864)
+      float ss = wave_sum(x0 * x0 + x1 * x1);
+      float rstd = rsqrtf(ss / (float)D + a.eps);
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(nw[2 * p])));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(nw[2 * p + 1])));
     }
+    uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+    float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
+    // llama.py:1026-1038, separate fp32 mul / sub / add (no fused multiply-add)
+    o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
+    o1 = f2bf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
+  }
+  if (!act) return;
+  const uint32_t packed = (uint32_t)o0 | ((uint32_t)o1 << 16);
+  if (h < H) {
+    *reinterpret_cast<uint32_t*>(a.q + ((int64_t)r * H + h) * D + 2 * p) = packed;
+  } else {
+    const int page = a.block_table[(int64_t)slot * a.max_pages + pos / KV_PAGE];
+    const int kh = (h < H + KVH) ? h - H : h - H - KVH;
+    bf16_t* pool = (h < H + KVH) ? a.kpool : a.vpool;
+    *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kh) * KV_PAGE + pos % KV_PAGE) * D + 2 * p) = packed;
   }
 }
 
 int launch_attn_prep(const AttnArgs& a, hipStream_t s) {
   FMI_REQUIRE(a.D % 2 == 0 && a.D <= 128 && a.D >= 16, "attn_prep: head_dim=%d unsupported", a.D);
-  hipLaunchKernelGGL(attn_prep_kernel, dim3(a.rows), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(attn_prep_kernel, dim3(a.rows, cdiv(a.H + 2 * a.KVH, 4)), dim3(256), 0, s, a);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -598,6 +630,211 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
   }
 }
 
+// Decode-time fusion of attn_prep + attn (one row per utterance, so a work-group only ever needs the
+// K/V of its own (slot, kv-head) -- no cross-work-group dependency).  grid (B, KVH), 8 waves.
+//   phase 1: k head (norm+RoPE -> cache + LDS), v head (-> cache + LDS), G q heads (norm+RoPE -> LDS)
+//   phase 2: tokens [0, pos) stream from the paged cache, 4 tokens per wave-load, 4 loads in flight per
+//            lane; token `pos` comes from LDS.  Online softmax per lane group, merged in-wave by
+//            shuffles, across waves through LDS.
+template <int D, int G>
+__global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
+  constexpr int NW = 8, LPT = D / 8, TPW = 64 / LPT, UN = 4;
+  __shared__ float s_q[G][D];
+  __shared__ float s_k[D], s_v[D];
+  __shared__ float s_m[NW][G], s_l[NW][G];
+  __shared__ float s_acc[NW][G][D];
+  const int r = blockIdx.x, kvh = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = a.row_slot[r];
+  const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
+  const int H = a.H, KVH = a.KVH;
+  const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
+  const bf16_t* src = a.qkv + (int64_t)r * (H + 2 * KVH) * D;
+
+  // ---- phase 1
+  for (int item = wave; item < G + 2; item += NW) {
+    const int h = item == 0 ? H + kvh : (item == 1 ? H + KVH + kvh : kvh * G + (item - 2));
+    const bool act = lane < D / 2;
+    const int p = act ? lane : 0;
+    uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+    float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
+    bf16_t o0 = (bf16_t)(raw & 0xffff), o1 = (bf16_t)(raw >> 16);
+    if (item != 1) {
+      const bf16_t* nw = (item == 0) ? a.knw : a.qnw;
+      float y0 = x0, y1 = x1;
+      if (nw) {
+        float ss = wave_sum(x0 * x0 + x1 * x1);
+        float rstd = rsqrtf(ss / (float)D + a.eps);
+        y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(nw[2 * p])));
+        y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(nw[2 * p + 1])));
+      }
+      uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+      float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
+      o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
+      o1 = f2bf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
+    }
+    if (act) {
+      if (item >= 2) {
+        s_q[item - 2][2 * p] = bf2f(o0);
+        s_q[item - 2][2 * p + 1] = bf2f(o1);
+      } else {
+        const int page = bt[pos / KV_PAGE];
+        bf16_t* pool = (item == 0) ? a.kpool : a.vpool;
+        *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kvh) * KV_PAGE + pos % KV_PAGE) * D + 2 * p) =
+            (uint32_t)o0 | ((uint32_t)o1 << 16);
+        float* dst = (item == 0) ? s_k : s_v;
+        dst[2 * p] = bf2f(o0);
+        dst[2 * p + 1] = bf2f(o1);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2
+  const int sub = lane / LPT, dl = lane % LPT;
+  const float scale = 1.0f / sqrtf((float)D);
+  float q[G][8];
+#pragma unroll
+  for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[gq][j] = s_q[gq][dl * 8 + j];
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int gq = 0; gq < G; ++gq) {
+    m[gq] = -1e30f;
+    l[gq] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[gq][j] = 0.f;
+  }
+
+  auto consume = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += q[gq][j] * kf[j];
+#pragma unroll
+      for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      if (valid) {
+        const float sc = d * scale;
+        const float mn = fmaxf(m[gq], sc);
+        const float corr = __expf(m[gq] - mn);
+        const float pr = __expf(sc - mn);
+        l[gq] = l[gq] * corr + pr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[gq][j] = acc[gq][j] * corr + pr * vf[j];
+        m[gq] = mn;
+      }
+    }
+  };
+
+  // cached tokens [0, pos): wave w takes token groups w, w+NW, ... of TPW tokens; UN groups per trip
+  const int n_groups = (pos + TPW - 1) / TPW;
+  for (int g0 = wave; g0 < n_groups; g0 += NW * UN) {
+    uint4 kv[UN], vv[UN];
+    bool valid[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int t = (g0 + u * NW) * TPW + sub;
+      valid[u] = t < pos;
+      const int tc = valid[u] ? t : 0;
+      const int page = bt[tc / KV_PAGE];
+      const int64_t base = (((int64_t)page * KVH + kvh) * KV_PAGE + (tc % KV_PAGE)) * D + dl * 8;
+      kv[u] = *reinterpret_cast<const uint4*>(a.kpool + base);
+      vv[u] = *reinterpret_cast<const uint4*>(a.vpool + base);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bf16_t* ke = reinterpret_cast<const bf16_t*>(&kv[u]);
+      const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv[u]);
+      float kf[8], vf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kf[j] = bf2f(ke[j]);
+        vf[j] = bf2f(ve[j]);
+      }
+      consume(kf, vf, valid[u]);
+    }
+  }
+  if (wave == 0) {  // the current token, straight from LDS (lane group 0 only)
+    float kf[8], vf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      kf[j] = s_k[dl * 8 + j];
+      vf[j] = s_v[dl * 8 + j];
+    }
+    consume(kf, vf, sub == 0);
+  }
+
+  // in-wave merge of the TPW lane-group states
+#pragma unroll
+  for (int off = LPT; off < 64; off <<= 1) {
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      const float mo = __shfl_xor(m[gq], off, 64), lo = __shfl_xor(l[gq], off, 64);
+      const float mn = fmaxf(m[gq], mo);
+      const float ws = __expf(m[gq] - mn), wo = __expf(mo - mn);
+      l[gq] = l[gq] * ws + lo * wo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float ao = __shfl_xor(acc[gq][j], off, 64);
+        acc[gq][j] = acc[gq][j] * ws + ao * wo;
+      }
+      m[gq] = mn;
+    }
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      if (dl == 0) {
+        s_m[wave][gq] = m[gq];
+        s_l[wave][gq] = l[gq];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_acc[wave][gq][dl * 8 + j] = acc[gq][j];
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < G * D; o += 512) {
+    const int gq = o / D, d = o % D;
+    float M = -1e30f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][gq]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float wgt = __expf(s_m[w][gq] - M);
+      L += s_l[w][gq] * wgt;
+      O += s_acc[w][gq][d] * wgt;
+    }
+    a.out[((int64_t)r * H + kvh * G + gq) * D + d] = f2bf(O / L);
+  }
+}
+
+template <int D>
+static int launch_attn_decode_d(const AttnArgs& a, hipStream_t s) {
+  const int G = a.H / a.KVH;
+  dim3 grid(a.rows, a.KVH), block(512);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 2>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 4>), grid, block, 0, s, a); break;
+    default: return set_error(FMI_EINVAL, "attn: GQA ratio %d unsupported", G);
+  }
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+int launch_attn_decode_fused(const AttnArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.H % a.KVH == 0, "attn: n_head %% n_local_heads");
+  switch (a.D) {
+    case 32: return launch_attn_decode_d<32>(a, s);
+    case 64: return launch_attn_decode_d<64>(a, s);
+    case 128: return launch_attn_decode_d<128>(a, s);
+    default: return set_error(FMI_EINVAL, "attn: head_dim %d unsupported (32/64/128)", a.D);
+  }
+}
+
 // fast-AR attention (llama.py:948-976), S <= num_codebooks, everything rounded through bf16 like
 // the reference's explicit matmul/softmax chain.  grid (B, KVH), 4 waves.
 __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
@@ -656,20 +893,24 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
     }
     const float q0 = rbf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
     const float q1 = rbf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
+    // all cached rows are fetched up front (unconditional, clamped) so the loads overlap
+    uint32_t kr[16], vr[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int tc = t < a.ncb ? t : a.ncb - 1;
+      kr[t] = *reinterpret_cast<const uint32_t*>(kc + (int64_t)tc * D + 2 * p);
+      vr[t] = *reinterpret_cast<const uint32_t*>(vc + (int64_t)tc * D + 2 * p);
+    }
     float sc[16];
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       sc[t] = 0.f;
       if (t <= pos) {
-        float k0, k1;
+        float k0 = bf2f((bf16_t)(kr[t] & 0xffff)), k1 = bf2f((bf16_t)(kr[t] >> 16));
         if (t == pos) {
           k0 = s_k[2 * p];
           k1 = s_k[2 * p + 1];
-        } else {
-          uint32_t kr = *reinterpret_cast<const uint32_t*>(kc + (int64_t)t * D + 2 * p);
-          k0 = bf2f((bf16_t)(kr & 0xffff));
-          k1 = bf2f((bf16_t)(kr >> 16));
         }
         float d = act ? (q0 * k0 + q1 * k1) : 0.f;
         d = wave_sum(d);
@@ -690,14 +931,10 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
     for (int t = 0; t < 16; ++t)
       if (t <= pos) {
         const float pr = rbf(sc[t] / sum);  // softmax output rounded to bf16
-        float v0, v1;
+        float v0 = bf2f((bf16_t)(vr[t] & 0xffff)), v1 = bf2f((bf16_t)(vr[t] >> 16));
         if (t == pos) {
           v0 = s_v[2 * p];
           v1 = s_v[2 * p + 1];
-        } else {
-          uint32_t vr = *reinterpret_cast<const uint32_t*>(vc + (int64_t)t * D + 2 * p);
-          v0 = bf2f((bf16_t)(vr & 0xffff));
-          v1 = bf2f((bf16_t)(vr >> 16));
         }
         o0 += pr * v0;
         o1 += pr * v1;

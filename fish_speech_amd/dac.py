@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference's codec seam, driving libfishmi.so through ctypes.
+
+Reference surface mirrored (fish_speech/models/dac/modded_dac.py): ``DAC.encode`` (874-923),
+``DAC.from_indices`` (925-927), attributes ``sample_rate``, ``frame_length``, ``device``,
+``parameters()`` -- what VQManager, the codec CLI (dac/inference.py:90,112) and the text2semantic CLI
+(inference.py:435,443) touch.  The convolutions, transformers and quantizer all run in the HIP
+kernels of csrc/dac_kernels.hip; torch is used for buffers and for folding weight-norm at load time
+(``torch._weight_norm``, the very function the reference's parametrization evaluates).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DacConfigC, check
+
+
+@dataclass
+class DacConfig:
+    """fish_speech/configs/modded_dac_vq.yaml."""
+
+    encoder_dim: int = 64
+    encoder_rates: Tuple[int, ...] = (2, 4, 8, 8)
+    decoder_dim: int = 1536
+    decoder_rates: Tuple[int, ...] = (8, 8, 4, 2)
+    n_codebooks: int = 9
+    codebook_size: int = 1024
+    semantic_codebook_size: int = 4096
+    codebook_dim: int = 8
+    downsample: Tuple[int, ...] = (2, 2)
+    tf_layers: int = 8
+    tf_ffn_mult: int = 3
+    tf_window: int = 128
+    enc_tf_layers: int = 4
+    enc_tf_window: int = 512
+    sample_rate: int = 44100
+
+    @classmethod
+    def from_any(cls, cfg) -> "DacConfig":
+        kw = {f: getattr(cfg, f) for f in cls.__dataclass_fields__ if hasattr(cfg, f)}
+        return cls(**kw)
+
+    @property
+    def latent_dim(self) -> int:
+        return self.encoder_dim * 2 ** len(self.encoder_rates)
+
+    @property
+    def frame_length(self) -> int:
+        return int(math.prod(self.encoder_rates)) * int(math.prod(self.downsample))
+
+    def to_c(self) -> DacConfigC:
+        c = DacConfigC()
+        c.encoder_dim, c.decoder_dim, c.latent_dim = self.encoder_dim, self.decoder_dim, self.latent_dim
+        c.encoder_rates = (C.c_int32 * 4)(*self.encoder_rates)
+        c.decoder_rates = (C.c_int32 * 4)(*self.decoder_rates)
+        c.n_codebooks, c.codebook_size = self.n_codebooks, self.codebook_size
+        c.semantic_codebook_size, c.codebook_dim = self.semantic_codebook_size, self.codebook_dim
+        c.downsample = (C.c_int32 * 2)(*self.downsample)
+        c.tf_layers, c.tf_heads = self.tf_layers, self.latent_dim // 64
+        c.tf_ffn, c.tf_window = self.latent_dim * self.tf_ffn_mult, self.tf_window
+        c.enc_tf_layers, c.enc_tf_window, c.sample_rate = self.enc_tf_layers, self.enc_tf_window, self.sample_rate
+        return c
+
+
+def fold_weight_norm(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """codec.pth keys -> plain weights: w = g * v / ||v|| over all dims but 0, for both weight-norm
+    spellings (parametrizations.weight.original0/1, modded_dac.py:554-556; weight_g/weight_v of the
+    third-party quantizer projections).  SURVEY.md A.6."""
+    out = {}
+    for k, v in state.items():
+        if k.endswith("parametrizations.weight.original1"):
+            base = k[: -len("parametrizations.weight.original1")]
+            out[base + "weight"] = torch._weight_norm(v.float(), state[base + "parametrizations.weight.original0"].float(), 0)
+        elif k.endswith("weight_v"):
+            base = k[: -len("weight_v")]
+            out[base + "weight"] = torch._weight_norm(v.float(), state[base + "weight_g"].float(), 0)
+        elif k.endswith("parametrizations.weight.original0") or k.endswith("weight_g"):
+            continue
+        elif "causal_mask" in k or "freqs_cis" in k:
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+def _rope_table(n_pos: int, n_elem: int = 64, base: float = 10000.0) -> torch.Tensor:
+    """modded_dac.py:442-452 (bf16 by default), built with torch so the table is the reference's."""
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
+    f = torch.outer(torch.arange(n_pos), freqs)
+    cis = torch.polar(torch.ones_like(f), f)
+    return torch.stack([cis.real, cis.imag], dim=-1).to(torch.bfloat16).reshape(n_pos, n_elem).contiguous()
+
+
+class MiDAC:
+    """DAC-shaped codec object (encode / from_indices) whose compute lives in libfishmi.so."""
+
+    def __init__(self, config=None, device="cuda:0"):
+        self.lib = _lib.load()
+        self.config = config if isinstance(config, DacConfig) else (DacConfig.from_any(config) if config else DacConfig())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.FishmiError("MiDAC needs a GPU device (no CPU fallback)")
+        torch.cuda.set_device(self.device)
+        self._c = self.config.to_c()
+        need = self.lib.fmi_dac_arena_bytes(C.byref(self._c))
+        if need < 0:
+            check(-1)
+        self.arena = torch.empty(need, dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        check(self.lib.fmi_dac_create(C.byref(self._c), C.c_void_p(self.arena.data_ptr()), need, C.byref(h)))
+        self._h = h
+        self.sample_rate = self.config.sample_rate
+        self.frame_length = self.config.frame_length
+        self.hop_length = int(math.prod(self.config.encoder_rates))
+        self._dtype_probe = torch.empty(0, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.fmi_dac_destroy(h)
+            self._h = None
+
+    def parameters(self) -> Iterable[torch.Tensor]:
+        yield self._dtype_probe
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True, assign: bool = False):
+        """Accepts codec.pth content (optionally wrapped / 'generator.'-prefixed like dac/inference.py:29-42)."""
+        if "state_dict" in state:
+            state = state["state_dict"]
+        if any("generator" in k for k in state):
+            state = {k.replace("generator.", ""): v for k, v in state.items() if "generator." in k}
+        folded = fold_weight_norm(state)
+        s = self._stream()
+        for name, t in folded.items():
+            t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            dims = (C.c_int64 * t.dim())(*t.shape)
+            rc = self.lib.fmi_dac_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.dim(), dims, 1, s)
+            if rc != 0 and not strict:
+                continue
+            check(rc)
+            torch.cuda.current_stream(self.device).synchronize()
+        tab = _rope_table(32768).to(self.device)
+        dims = (C.c_int64 * 2)(*tab.shape)
+        check(self.lib.fmi_dac_load_tensor(self._h, b"rope_table", C.c_void_p(tab.data_ptr()), 2, dims, 1, s))
+        check(self.lib.fmi_dac_finalize_weights(self._h, s))
+        torch.cuda.current_stream(self.device).synchronize()
+        return self
+
+    def weights_ready(self):
+        check(self.lib.fmi_dac_weights_ready(self._h))
+
+    @classmethod
+    def from_state_dict(cls, config, state, device="cuda:0") -> "MiDAC":
+        return cls(config, device=device).load_state_dict(state)
+
+    # ---- DAC.encode (modded_dac.py:874-923)
+    @torch.no_grad()
+    def encode(self, audio_data: torch.Tensor, audio_lengths: Optional[torch.Tensor] = None, n_quantizers=None, **kw):
+        if audio_data.ndim == 2:
+            audio_data = audio_data.unsqueeze(1)
+        length = audio_data.shape[-1]
+        fl = self.frame_length
+        right = math.ceil(length / fl) * fl - length
+        audio = torch.nn.functional.pad(audio_data.to(device=self.device, dtype=torch.float32), (0, right)).contiguous()
+        if audio_lengths is None:
+            audio_lengths = torch.tensor([length + right], device=self.device, dtype=torch.long)
+        B, _, N = audio.shape
+        T = N // fl
+        idx = torch.empty(B, self.config.n_codebooks + 1, T, dtype=torch.int64, device=self.device)
+        check(self.lib.fmi_dac_encode(self._h, C.c_void_p(audio.data_ptr()), B, N, C.c_void_p(idx.data_ptr()), self._stream()))
+        lens = torch.ceil(audio_lengths.to(self.device) / fl).long()
+        self._keep = audio
+        return idx, lens
+
+    # ---- DAC.from_indices (modded_dac.py:925-927).  Clamps `indices` in place like rvq.py:354-359.
+    @torch.no_grad()
+    def from_indices(self, indices: torch.Tensor) -> torch.Tensor:
+        if indices.device != self.device or indices.dtype != torch.int64 or not indices.is_contiguous():
+            work = indices.to(device=self.device, dtype=torch.int64).contiguous()
+        else:
+            work = indices
+        B, nb, T = work.shape
+        if nb != self.config.n_codebooks + 1:
+            raise ValueError(f"expected {self.config.n_codebooks + 1} codebooks, got {nb}")
+        out = torch.empty(B, 1, T * self.frame_length, dtype=torch.float32, device=self.device)
+        check(self.lib.fmi_dac_decode(self._h, C.c_void_p(work.data_ptr()), B, T, C.c_void_p(out.data_ptr()), self._stream()))
+        if work is not indices:
+            try:
+                indices.copy_(work)  # the reference mutates its argument; keep that visible to the caller
+            except Exception:
+                pass
+        self._keep = work
+        return out
+
+    def debug_z(self, B: int) -> torch.Tensor:
+        """quantizer.decode output (B, latent_dim, 4T) of the last from_indices call (parity tap)."""
+        from .dual_ar import _from_ptr
+
+        p, cc, ll = C.c_void_p(), C.c_int(), C.c_int()
+        check(self.lib.fmi_dac_debug_z(self._h, C.byref(p), C.byref(cc), C.byref(ll)))
+        torch.cuda.synchronize(self.device)
+        return _from_ptr(p.value, (B, cc.value, ll.value), torch.float32, self.device).clone()
+
+
+def smoke_check():
+    """Used by __graft_entry__.smoke(): tiny codec, from_indices vs the CPU oracle."""
+    from oracle import dac as D
+
+    cfg = D.small_config()
+    state = D.make_synthetic_state(cfg, seed=11)
+    codec = MiDAC.from_state_dict(DacConfig.from_any(cfg), state)
+    codes = D.make_codes(cfg, 1, 4, seed=2)
+    got = codec.from_indices(codes.clone().cuda()).cpu()
+    want = D.DacOracle(cfg, state).from_indices(codes.clone())
+    rms = float((got - want).pow(2).mean().sqrt())
+    assert rms <= 1e-4, f"codec waveform RMS error {rms}"
+    print(f"smoke: codec from_indices RMS error vs oracle {rms:.2e}")

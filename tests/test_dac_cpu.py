@@ -1,0 +1,71 @@
+"""CPU suite for the codec oracle: against the fixtures the unmodified reference DAC produced
+(tests/golden/dac_small.npz, oracle/gen_golden_dac.py) and structural properties of the path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dac as D
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dac_small.npz")
+
+
+@pytest.fixture(scope="module")
+def case():
+    z = np.load(GOLD)
+    cfg = D.small_config()
+    return cfg, D.make_synthetic_state(cfg, seed=int(z["state_seed"])), z
+
+
+def test_oracle_encode_matches_reference_codes(case):
+    cfg, state, z = case
+    codes, lens = D.DacOracle(cfg, state).encode(torch.from_numpy(z["audio"]), torch.tensor([z["audio"].shape[-1]]))
+    assert np.array_equal(codes.numpy(), z["codes"]) and np.array_equal(lens.numpy(), z["lens"])
+    assert codes.dtype == torch.int64 and codes.shape[1] == cfg.n_codebooks + 1
+
+
+def test_oracle_decode_matches_reference_waveform(case):
+    cfg, state, z = case
+    orc = D.DacOracle(cfg, state)
+    got = orc.from_indices(torch.from_numpy(z["codes"]).clone())
+    assert float((got - torch.from_numpy(z["decoded"])).pow(2).mean().sqrt()) <= 1e-6
+    rnd = torch.from_numpy(z["rnd_codes"]).clone()
+    zq = orc.dequantize(rnd)
+    assert np.array_equal(rnd.numpy(), z["rnd_codes_clamped"])  # in-place clamp, rvq.py:354-359
+    assert float((zq - torch.from_numpy(z["rnd_z"])).abs().max()) <= 1e-5
+    got = orc.from_indices(torch.from_numpy(z["rnd_codes"]).clone())
+    assert float((got - torch.from_numpy(z["rnd_decoded"])).pow(2).mean().sqrt()) <= 1e-6
+    assert got.shape == (2, 1, 5 * cfg.frame_length) and float(got.abs().max()) < 1.0
+
+
+def test_decoder_is_causal_prefix_consistent(case):
+    """All convolutions are causal and attention is windowed-causal: decoding a prefix of the codes
+    gives the prefix of the waveform (the property streaming decode relies on)."""
+    cfg, state, z = case
+    orc = D.DacOracle(cfg, state)
+    codes = D.make_codes(cfg, 1, 6, seed=8)
+    full = orc.from_indices(codes.clone())
+    part = orc.from_indices(codes[:, :, :4].clone())
+    assert float((full[..., : 4 * cfg.frame_length] - part).abs().max()) <= 1e-5
+
+
+def test_state_table_and_weight_norm_fold(case):
+    cfg, state, _ = case
+    folded = D.fold_weight_norm(state)
+    assert not any(k.endswith(("weight_g", "weight_v", "original0", "original1")) for k in folded)
+    k = "decoder.model.1.block.1.conv"
+    v, g = state[k + ".parametrizations.weight.original1"], state[k + ".parametrizations.weight.original0"]
+    want = g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+    assert torch.allclose(folded[k + ".weight"], want, rtol=1e-6, atol=1e-7)
+    full = D.state_shapes(D.DacConfig())
+    n_params = sum(int(np.prod(s)) for s in full.values())
+    assert 385e6 < n_params < 400e6  # 391.4 M parameters with the yaml's values
+
+
+def test_product_shim_fold_equals_oracle_fold(case):
+    from fish_speech_amd.dac import fold_weight_norm
+
+    cfg, state, _ = case
+    a, b = fold_weight_norm(state), D.fold_weight_norm(state)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)

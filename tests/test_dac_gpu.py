@@ -1,0 +1,116 @@
+"""GPU parity tests of the codec: MiDAC (C ABI -> HIP kernels) against the fixtures written by the
+unmodified reference DAC (tests/golden/dac_small.npz) and against the CPU oracle at full size.
+
+Tolerances (north_star): codebook indices bit-exact, waveform RMS error <= 1e-4 (fp32 path; only the
+fp32 summation order differs from the CPU convolution)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dac as D
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dac_small.npz")
+
+
+def rms(a, b):
+    return float((a.float().cpu() - b.float().cpu()).pow(2).mean().sqrt())
+
+
+@pytest.fixture(scope="module")
+def small():
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    z = np.load(GOLD)
+    cfg = D.small_config()
+    state = D.make_synthetic_state(cfg, seed=int(z["state_seed"]))
+    return cfg, state, z, MiDAC.from_state_dict(DacConfig.from_any(cfg), state, device=DEV)
+
+
+@pytest.fixture(scope="module")
+def full():
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg = D.DacConfig()
+    state = D.make_synthetic_state(cfg, seed=3)
+    return cfg, state, MiDAC.from_state_dict(DacConfig.from_any(cfg), state, device=DEV)
+
+
+def test_from_indices_matches_reference_golden(small):
+    cfg, state, z, codec = small
+    got = codec.from_indices(torch.from_numpy(z["codes"]).to(DEV))
+    assert got.shape == z["decoded"].shape and got.dtype == torch.float32
+    assert rms(got, torch.from_numpy(z["decoded"])) <= 1e-4
+    idx = torch.from_numpy(z["rnd_codes"]).to(DEV)
+    got = codec.from_indices(idx)
+    assert np.array_equal(idx.cpu().numpy(), z["rnd_codes_clamped"])  # in-place clamp (rvq.py:354-359)
+    assert rms(codec.debug_z(2), torch.from_numpy(z["rnd_z"])) <= 1e-5
+    assert rms(got, torch.from_numpy(z["rnd_decoded"])) <= 1e-4
+
+
+def test_encode_matches_reference_golden_codes(small):
+    cfg, state, z, codec = small
+    audio = torch.from_numpy(z["audio"]).to(DEV)
+    codes, lens = codec.encode(audio, torch.tensor([audio.shape[-1]], device=DEV))
+    assert codes.dtype == torch.int64 and np.array_equal(lens.cpu().numpy(), z["lens"])
+    assert np.array_equal(codes.cpu().numpy(), z["codes"])
+
+
+def test_encode_decode_roundtrip_shapes_and_ragged_padding(small):
+    cfg, state, z, codec = small
+    for n in (1, cfg.frame_length - 1, cfg.frame_length, 2 * cfg.frame_length + 5):
+        audio = 0.1 * torch.randn(2, 1, n, generator=torch.Generator().manual_seed(n)).to(DEV)
+        codes, lens = codec.encode(audio, torch.tensor([n, max(1, n // 2)], device=DEV))
+        T = -(-n // cfg.frame_length)
+        assert codes.shape == (2, cfg.n_codebooks + 1, T)
+        assert lens.tolist() == [T, -(-max(1, n // 2) // cfg.frame_length)]
+        assert int(codes[:, 0].max()) < cfg.semantic_codebook_size and int(codes[:, 1:].max()) < cfg.codebook_size
+        wav = codec.from_indices(codes)
+        assert wav.shape == (2, 1, T * cfg.frame_length) and bool(torch.isfinite(wav).all())
+        want_codes, _ = D.DacOracle(cfg, state).encode(audio.cpu(), torch.tensor([n, max(1, n // 2)]))
+        assert torch.equal(codes.cpu(), want_codes)
+
+
+def test_full_size_from_indices_vs_oracle(full):
+    """yaml-sized codec (391 M parameters), 2 utterances x 3 frames."""
+    cfg, state, codec = full
+    codes = D.make_codes(cfg, 2, 3, seed=5)
+    got = codec.from_indices(codes.clone().to(DEV))
+    want = D.DacOracle(cfg, state).from_indices(codes.clone())
+    zt = codec.debug_z(2)
+    zw = D.DacOracle(cfg, state).dequantize(codes.clone())
+    assert rms(zt, zw) <= 1e-4 * float(zw.pow(2).mean().sqrt())
+    e = rms(got, want)
+    print("full-size waveform RMS error", e, "signal RMS", float(want.pow(2).mean().sqrt()))
+    assert e <= 1e-4
+
+
+def test_full_size_encode_vs_oracle(full):
+    cfg, state, codec = full
+    g = torch.Generator().manual_seed(9)
+    n = cfg.frame_length * 2 - 300
+    t = torch.arange(n) / cfg.sample_rate
+    audio = (0.3 * torch.sin(2 * np.pi * 220 * t) + 0.05 * torch.randn(n, generator=g)).view(1, 1, n)
+    codes, lens = codec.encode(audio.to(DEV), torch.tensor([n], device=DEV))
+    want, wl = D.DacOracle(cfg, state).encode(audio, torch.tensor([n]))
+    assert torch.equal(lens.cpu(), wl)
+    agree = float((codes.cpu() == want).float().mean())
+    print("full-size encode: codes agreeing with the oracle:", agree)
+    assert torch.equal(codes.cpu(), want)
+
+
+def test_causal_prefix_and_batch_invariance_at_10s(full):
+    """Size-independent properties at the BASELINE length (215 frames = 10 s): the decoder is causal
+    (all convs causal, attention windowed-causal), so decoding a prefix of the codes yields the
+    prefix of the waveform; and an utterance decodes to the same samples alone or in a batch."""
+    cfg, state, codec = full
+    codes = D.make_codes(cfg, 2, 215, seed=6).to(DEV)
+    both = codec.from_indices(codes.clone())
+    assert both.shape == (2, 1, 215 * 2048) and bool(torch.isfinite(both).all()) and float(both.abs().max()) <= 1.0
+    one = codec.from_indices(codes[1:2].clone())
+    assert torch.equal(one[0], both[1])
+    part = codec.from_indices(codes[:1, :, :100].clone())
+    assert float((part[0, 0] - both[0, 0, : 100 * 2048]).abs().max()) <= 2e-5
