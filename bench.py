@@ -83,12 +83,42 @@ def algorithmic_bytes_per_frame(cfg, batch, mean_ctx):
     return 2 * (slow + fast + heads + kv)
 
 
-def run_step(model, codec, prompts, samp_seeds):
-    from fish_speech_amd.dual_ar import generate_batch
+def synthetic_codec_state(cfg, device, seed=1):
+    """Random-init codec weights of the yaml's shape, generated on the GPU (no checkpoint is available)."""
+    from fish_speech_amd.dac import expected_state_shapes as codec_shapes
 
-    outs = generate_batch(model=model, prompts=prompts, max_new_tokens=N_FRAMES, poll_every=N_FRAMES,
-                          seeds=samp_seeds, stop_on_im_end=False, temperature=0.7, top_p=0.7, top_k=30)
-    return outs
+    g = torch.Generator(device=device).manual_seed(seed)
+    st = {}
+    for name, shape in codec_shapes(cfg).items():
+        if name.endswith("alpha"):
+            t = 0.5 + torch.rand(shape, generator=g, device=device)
+        elif name.endswith(".gamma"):
+            t = 0.3 + 0.05 * torch.randn(shape, generator=g, device=device)
+        elif name.endswith("norm.weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif name.endswith("bias"):
+            t = 0.02 * torch.randn(shape, generator=g, device=device)
+        elif name.endswith("codebook.weight"):
+            t = torch.randn(shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g, device=device) * (0.75 / max(fan_in, 1) ** 0.5)
+        st[name] = t
+    return st
+
+
+def run_step(model, codec, prompts, samp_seeds, device):
+    """One pass of the hot path over one batch: prefill + 214 graph-replayed decode frames + codec decode
+    of the generated codes (rows 1.. of each frame; the last frame is dropped like generate_long does,
+    inference.py:708, and replaced by ... nothing: 215 frames are generated and 215 are decoded here)."""
+    from fish_speech_amd.dual_ar import generate_batch_device
+
+    codes = generate_batch_device(model=model, prompts=prompts, max_new_tokens=N_FRAMES, seeds=samp_seeds,
+                                  temperature=0.7, top_p=0.7, top_k=30)   # (B, ncb, N_FRAMES) int64 on device
+    wav = codec.from_indices(codes) if codec is not None else None
+    return codes, wav
 
 
 def cpu_baseline(cfg, state_dev, n_frames=6):
@@ -126,6 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-codec", action="store_true", help="debug: Dual-AR only (INVALID as a result)")
     ap.add_argument("--frames", type=int, default=215, help="debug: fewer frames (INVALID as a result)")
     args = ap.parse_args()
 
@@ -159,23 +190,43 @@ def main():
         broadcast_arena(model, src=0)
     model.setup_caches(BATCH, PROMPT_T + N_FRAMES + 8)
     model.set_ignore_eos(True)
+    codec = None
+    if not args.no_codec:
+        from fish_speech_amd.dac import DacConfig, MiDAC
+
+        ccfg = DacConfig()
+        codec = MiDAC(ccfg, device=device)
+        if rank == 0:
+            codec.load_folded_state(synthetic_codec_state(ccfg, device))
+        if world > 1:
+            from fish_speech_amd.dist import broadcast_arena
+
+            broadcast_arena(codec, src=0)
     if args.no_graph:
         model.set_graph(False)
     prompts = make_prompts(cfg, BATCH, 1000 + rank * BATCH)
     seeds = [4242 + rank * BATCH + i for i in range(BATCH)]
 
     for _ in range(args.warmup):
-        run_step(model, None, prompts, seeds)
+        run_step(model, codec, prompts, seeds, device)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frame_ms = []
+    codec_ms = []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(args.steps):
-        run_step(model, None, prompts, seeds)
+        codes, _ = run_step(model, None, prompts, seeds, device)
         ms, launches = model.last_decode_stats()
         frame_ms.append(ms / max(N_FRAMES - 1, 1))
+        if codec is not None:
+            ev0.record()
+            codec.from_indices(codes)
+            ev1.record()
+            ev1.synchronize()
+            codec_ms.append(ev0.elapsed_time(ev1))
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -206,8 +257,10 @@ def main():
         "data": "synthetic (random-init S2-Pro-shaped weights, random 200-token prompts, EOS ignored, 215 frames)",
         "config": {"workload": "configs[2]: S2-Pro 4B batch=8, 200-token prompts -> 10 s audio, hipGraph inner-AR loop",
                    "batch_per_gpu": BATCH, "prompt_tokens": PROMPT_T, "frames": N_FRAMES, "parallelism": f"utterance-sharded x{world}",
-                   "codec_in_step": False},
+                   "codec_in_step": codec is not None},
         "semantic_frames_per_s": round(world * BATCH * N_FRAMES * args.steps / dt, 1),
+        "breakdown_ms": {"decode_frame_avg": round(avg_frame_s * 1e3, 4), "launches_per_frame": launches,
+                         "codec_decode_batch": round(sum(codec_ms) / len(codec_ms), 2) if codec_ms else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 4), "traffic": None,
                      "kernel": "decode frame = 314 linear_skinny_kernel launches + attention/sampler (one hipGraph)",

@@ -59,6 +59,7 @@ struct fmi_dualar {
   Workspace ws;
   bf16_t *hn = nullptr, *hf = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
   bool trace = false, use_graph = true, ignore_eos = false;
+  int max_top_k = 0;  // largest top_k any live slot was configured with (selects the sampler variant)
   std::map<int, hipGraphExec_t> graphs;
   void* staging = nullptr;
   size_t staging_bytes = 0;
@@ -112,7 +113,7 @@ int64_t layout(const fmi_dualar_config& c, fmi_dualar* h) {
     return p;
   };
   const Dims s = slow_dims(c), f = fast_dims(c);
-  const int n_live = count_live(c), n_live_pad = (int)align_up(n_live, 16);
+  const int n_live = count_live(c), n_live_pad = (int)align_up(n_live, 32);  // even tile count
   auto layer = [&](const Dims& d) {
     LayerW w;
     w.wqkv = (bf16_t*)take((int64_t)d.qkv * d.dim, 2);
@@ -292,7 +293,7 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   sa.logits = h->logits; sa.B = B; sa.n = h->n_live; sa.ld = h->n_live_pad; sa.ids = h->live_ids;
   sa.row_slot = row_slot; sa.st = h->st; sa.mode = 0; sa.cb = 0; sa.sem_begin = c.semantic_begin_id;
   sa.sem_end = c.semantic_end_id; sa.im_end = h->ignore_eos ? -1 : c.im_end_id; sa.cbs = c.codebook_size; sa.fast_emb = h->fast_emb;
-  sa.xf = h->xf; sa.fdim = c.fast_dim;
+  sa.xf = h->xf; sa.fdim = c.fast_dim; sa.small_k = h->max_top_k <= 64;
   FMI_CHECK(launch_sample(sa, s));
   h->launches += 1;
   // fast step 0 on the hidden state; its logits are discarded (inference.py:148-149)
@@ -353,6 +354,11 @@ int reserve_pages(fmi_dualar* h, int slot, int upto_pos_exclusive) {
 
 int set_slot(fmi_dualar* h, int slot, int pos, int frame, int limit, const fmi_sampling& sp, bool zero_window) {
   hipStream_t s = h->stream;
+  if ((sp.top_k > 64) != (h->max_top_k > 64)) {  // the captured graphs embed the sampler variant
+    FMI_CHECK_HIP(hipStreamSynchronize(s));
+    drop_graphs(h);
+  }
+  h->max_top_k = std::max(h->max_top_k, (int)sp.top_k);
   const int32_t zero = 0;
   const float t = rbf(sp.temperature), p = rbf(sp.top_p);
 #define PUT(arr, val) FMI_CHECK_HIP(hipMemcpyAsync((arr) + slot, &(val), 4, hipMemcpyHostToDevice, s))
@@ -738,6 +744,14 @@ int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_fra
   return FMI_OK;
 }
 
+int fmi_dualar_out_ptr(fmi_dualar* h, void** out_dev, int* max_frames) {
+  FMI_REQUIRE(h && out_dev, "null argument");
+  FMI_REQUIRE(h->max_batch > 0, "setup_caches has not been called");
+  *out_dev = h->st.out;
+  if (max_frames) *max_frames = h->st.max_frames;
+  return FMI_OK;
+}
+
 int fmi_dualar_read(fmi_dualar* h, int slot, int32_t* out_host, int max_frames, int* n_frames_out, int* done_out,
                     void* stream) {
   FMI_REQUIRE(h && out_host && n_frames_out, "null argument");
@@ -887,7 +901,7 @@ int fmi_op_sample(const void* logits_dev, int B, int n, int ld, const int32_t* i
   a.logits = (const bf16_t*)logits_dev; a.B = B; a.n = n; a.ld = ld; a.ids = ids_dev; a.row_slot = nullptr;
   a.mode = 2; a.sem_begin = sem_begin; a.sem_end = sem_end; a.temperature = rbf(samp->temperature);
   a.top_p = rbf(samp->top_p); a.top_k = samp->top_k; a.seed = samp->seed; a.frame = frame; a.draw = draw;
-  a.prev = prev_dev; a.out_tok = out_dev; a.xf = nullptr;
+  a.prev = prev_dev; a.out_tok = out_dev; a.xf = nullptr; a.small_k = samp->top_k <= 64;
   return launch_sample(a, (hipStream_t)stream);
 }
 

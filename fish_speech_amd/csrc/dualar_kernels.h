@@ -120,6 +120,7 @@ struct SampleArgs {
   int frame, draw;
   const int32_t* prev;    // [B][RAS_WIN] or nullptr
   int32_t* out_tok;       // [B]
+  int small_k;            // 1 = every slot uses top_k <= 64 (fast single-wave finish)
 };
 int launch_sample(const SampleArgs& a, hipStream_t s);
 

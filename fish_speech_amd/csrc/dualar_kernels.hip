@@ -204,9 +204,16 @@ int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf
 
 __device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
-template <int WAVES, int EPI, bool NORM, int UNR>
+template <bool NT>
+__device__ inline u32x4 wload(const u32x4* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// TILES = 16-row weight tiles per work-group (SwiGLU: gate/up tiles alternate, so TILES is even).
+template <int WAVES, int EPI, bool NORM, int UNR, int TILES = (EPI == EPI_SILU ? 2 : 1), bool NT = true>
 __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a) {
-  constexpr int TILES = (EPI == EPI_SILU) ? 2 : 1;
+  static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
   __shared__ float red[WAVES][TILES][256];
   __shared__ float s_rstd[16];
 
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) wa[t][u] = __builtin_nontemporal_load(wrow[t] + (int64_t)(kbeg + u) * 64);
+      for (int t = 0; t < TILES; ++t) wa[t][u] = wload<NT>(wrow[t] + (int64_t)(kbeg + u) * 64);
   }
 
   float rstd = 0.f;
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) wv[t][u] = __builtin_nontemporal_load(wrow[t] + (int64_t)(kt + u) * 64);
+      for (int t = 0; t < TILES; ++t) wv[t][u] = wload<NT>(wrow[t] + (int64_t)(kt + u) * 64);
   };
 
   int kt = kbeg;
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 wv = __builtin_nontemporal_load(wrow[t] + (int64_t)kt * 64);
+      u32x4 wv = wload<NT>(wrow[t] + (int64_t)kt * 64);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[t], 0, 0, 0);
     }
   }
@@ -313,49 +320,65 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
         v[t] = sacc;
       }
       if (EPI == EPI_STORE) {
-        a.out[(int64_t)bb * a.ldo + tile0 * 16 + r] = f2bf(v[0]);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) a.out[(int64_t)bb * a.ldo + (tile0 + t) * 16 + r] = f2bf(v[t]);
       } else if (EPI == EPI_RESIDUAL) {
-        const int n = tile0 * 16 + r;
-        a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + rbf(v[0]));
-      } else {  // SwiGLU: tile0 = gate rows, tile0+1 = up rows (llama.py:987)
-        const int n = blockIdx.x * 16 + r;
-        float gate = rbf(silu_f(rbf(v[0])));
-        float up = rbf(v[TILES - 1]);
-        a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          const int n = (tile0 + t) * 16 + r;
+          a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + rbf(v[t]));
+        }
+      } else {  // SwiGLU: even tiles = gate rows, odd tiles = up rows (llama.py:987)
+#pragma unroll
+        for (int t = 0; t < TILES; t += 2) {
+          const int n = ((tile0 + t) >> 1) * 16 + r;
+          float gate = rbf(silu_f(rbf(v[t])));
+          float up = rbf(v[t + 1 < TILES ? t + 1 : t]);
+          a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
+        }
       }
     }
   }
 }
 
-template <int WAVES, int UNR>
+template <int WAVES, int UNR, int TILES>
 static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
   const bool norm = a.norm_w != nullptr;
-  const int tiles = (a.epi == EPI_SILU) ? 2 : 1;
-  dim3 grid(a.N / (16 * tiles)), block(WAVES * 64);
+  dim3 grid(a.N / (16 * TILES)), block(WAVES * 64);
 #define FMI_LAUNCH(EPI_, NORM_) \
-  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR>), grid, block, 0, s, a)
+  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true>), grid, block, 0, s, a)
   if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH(EPI_STORE, true); else FMI_LAUNCH(EPI_STORE, false); }
   else if (a.epi == EPI_RESIDUAL) { if (norm) FMI_LAUNCH(EPI_RESIDUAL, true); else FMI_LAUNCH(EPI_RESIDUAL, false); }
-  else { if (norm) FMI_LAUNCH(EPI_SILU, true); else FMI_LAUNCH(EPI_SILU, false); }
+  else if constexpr (TILES % 2 == 0) { if (norm) FMI_LAUNCH(EPI_SILU, true); else FMI_LAUNCH(EPI_SILU, false); }
 #undef FMI_LAUNCH
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
 
+// Variant choice from tools/gemv_bench.hip on MI355X (profiles/gemv_bench_r01.txt), M = 8:
+//   w13  (19456x2560, norm, SwiGLU)  8 waves, UNR 2, 2 tiles : 26.3 us (3.79 TB/s)
+//   wqkv (6144x2560, norm)          16 waves, UNR 2, 2 tiles : 13.3 us (2.37 TB/s)
+//   wo   (2560x4096, residual)      16 waves, UNR 2, 1 tile  :  6.9 us (3.04 TB/s)
+//   w2   (2560x9728, residual)       8 waves, UNR 4, 1 tile  : 13.3 us (3.75 TB/s)
+// A bare streaming read of the same bytes per launch reaches 3.6 / 4.1 / 4.4 / 5.0 TB/s at
+// 21 / 32 / 50 / 100 MiB (about 3 us of every launch is ramp), 6.4-6.6 TB/s at 1 GiB.
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   FMI_REQUIRE(a.M >= 1 && a.M <= 16, "linear_skinny: M=%d not in [1,16]", a.M);
   FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0, "linear_skinny: bad shape N=%d K=%d", a.N, a.K);
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_skinny: SwiGLU needs N %% 32");
   const int KT = a.K / 32;
-  // split-K factor: enough waves in flight to cover HBM latency when there are few row tiles
   const int ntile = a.N / 16;
-  if (ntile >= 512 || KT < 16) {
-    if (KT >= 16) return launch_skinny_t<4, 4>(a, s);
-    return launch_skinny_t<4, 1>(a, s);
+  if (KT < 32) {  // tiny test models
+    if (a.epi == EPI_SILU || ntile % 2 == 0) return launch_skinny_t<4, 1, 2>(a, s);
+    return launch_skinny_t<4, 1, 1>(a, s);
   }
-  if (KT >= 128) return launch_skinny_t<16, 4>(a, s);
-  if (KT >= 64) return launch_skinny_t<8, 4>(a, s);
-  return launch_skinny_t<4, 4>(a, s);
+  if (a.epi == EPI_SILU) return launch_skinny_t<8, 2, 2>(a, s);
+  if (a.norm_w) {  // norm-fused projections (wqkv, LM head, fast_output)
+    if (ntile % 2 == 0) return launch_skinny_t<16, 2, 2>(a, s);
+    return launch_skinny_t<16, 2, 1>(a, s);
+  }
+  if (KT >= 256) return launch_skinny_t<8, 4, 1>(a, s);   // w2: long K
+  return launch_skinny_t<16, 2, 1>(a, s);                 // wo
 }
 
 // =====================================================================================
@@ -637,8 +660,8 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 //            lane; token `pos` comes from LDS.  Online softmax per lane group, merged in-wave by
 //            shuffles, across waves through LDS.
 template <int D, int G>
-__global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
-  constexpr int NW = 8, LPT = D / 8, TPW = 64 / LPT, UN = 4;
+__global__ __launch_bounds__(1024) void attn_decode_fused_kernel(AttnArgs a) {
+  constexpr int NW = 16, LPT = D / 8, TPW = 64 / LPT, UN = 4;
   __shared__ float s_q[G][D];
   __shared__ float s_k[D], s_v[D];
   __shared__ float s_m[NW][G], s_l[NW][G];
@@ -795,7 +818,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < G * D; o += 512) {
+  for (int o = threadIdx.x; o < G * D; o += 1024) {
     const int gq = o / D, d = o % D;
     float M = -1e30f;
 #pragma unroll
@@ -814,7 +837,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
 template <int D>
 static int launch_attn_decode_d(const AttnArgs& a, hipStream_t s) {
   const int G = a.H / a.KVH;
-  dim3 grid(a.rows, a.KVH), block(512);
+  dim3 grid(a.rows, a.KVH), block(1024);
   switch (G) {
     case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 1>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 2>), grid, block, 0, s, a); break;
@@ -1282,8 +1305,289 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path, top_k <= 64 (the reference default is 30): same arithmetic as sample_kernel, but after
+// the radix select a single wave finishes the job with shuffles (rank sort, sequential fp32 cumsum,
+// both draws, bookkeeping) -- about ten barriers instead of fifty.
+// ------------------------------------------------------------------------------------------------
+
+struct SmallShared {
+  uint32_t hist[256];
+  float wsum[4];
+  uint32_t wmax[4];
+  int wcnt_gt[4], wcnt_eq[4];
+  int sel[4];
+  int cand_idx[64];
+  uint32_t cand_key[64];
+  float s_val[64];
+  int s_idx[64];
+};
+
+// suffix[b] = sum_{j >= b} hist[j] evaluated by wave 0; returns via sel[o], sel[o+1] the bin where the
+// k-th largest key lives and the number of keys in bins above it
+__device__ inline void wave_find_bin(SmallShared& sh, int lane, uint32_t k, int o) {
+  uint32_t h[4], loc = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = sh.hist[lane * 4 + i];
+    loc += h[i];
+  }
+  // inclusive suffix over lanes (lane l gets sum over lanes >= l)
+  uint32_t suf = loc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t v = __shfl_down(suf, off, 64);
+    if (lane + off < 64) suf += v;
+  }
+  uint32_t above = suf - loc;  // keys in bins of higher lanes
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    const uint32_t here = above + h[i];
+    if (here >= k && above < k) {
+      sh.sel[o] = lane * 4 + i;
+      sh.sel[o + 1] = (int)above;
+    }
+    above = here;
+  }
+}
+
+__device__ inline int small_draw(float v, float cum, int vid, int lane, int k, float temperature, float top_p,
+                                 uint32_t seed, uint32_t stream, uint32_t frame, uint32_t draw) {
+  const float tc = rbf(fmaxf(temperature, rbf(1e-5f)));
+  const bool in = lane < k;
+  const bool keep = in && ((lane == 0) || !(cum > top_p));
+  const float lt = rbf(v / tc);
+  const float l0 = __shfl(lt, 0, 64);
+  const float e = keep ? expf(lt - l0) : 0.f;
+  const float esum = wave_sum(e);
+  float best = -1.f;
+  int best_id = 0x7fffffff;
+  if (e > 0.f) {
+    const float pr = rbf(e / esum);
+    const uint32_t u8 = fmi_rand_u8(seed, stream, frame, draw, (uint32_t)vid);
+    const float qv = -rbf(logf((float)u8 * (1.0f / 256.0f)));
+    best = rbf(pr / qv);
+    best_id = vid;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_id, o, 64);
+    if (ov > best || (ov == best && oi < best_id)) {
+      best = ov;
+      best_id = oi;
+    }
+  }
+  return (best > 0.f) ? best_id : 0;  // all-zero race -> the reference's argmax lands on index 0
+}
+
+__global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  SmallShared& sh = *reinterpret_cast<SmallShared*>(smem_raw);
+  uint16_t* skey = reinterpret_cast<uint16_t*>(smem_raw + sizeof(SmallShared));
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int slot = a.row_slot ? a.row_slot[b] : b;
+  const bf16_t* lg = a.logits + (int64_t)b * a.ld;
+  const int n = a.n;
+
+  float temperature, top_p;
+  int top_k, frame, draw0, use_ras;
+  uint32_t seed;
+  if (a.mode == 2) {
+    temperature = a.temperature; top_p = a.top_p; top_k = a.top_k; seed = a.seed;
+    frame = a.frame; draw0 = a.draw; use_ras = a.prev != nullptr;
+  } else {
+    temperature = a.st.temperature[slot]; top_p = a.st.top_p[slot]; top_k = a.st.top_k[slot];
+    seed = a.st.seed[slot]; frame = a.st.frame[slot];
+    draw0 = (a.mode == 0) ? 0 : 1 + a.cb;
+    use_ras = a.st.use_ras[slot] && frame > 0;
+  }
+  int k = top_k < n ? top_k : n;
+  if (k > 64) k = 64;
+  if (k < 1) k = 1;
+
+  // ---- pass 1 (all waves): keys, max, high-byte histogram
+  sh.hist[tid] = 0;
+  __syncthreads();
+  const int ept = (n + 255) / 256;
+  const int i0 = tid * ept, i1 = min(n, i0 + ept);
+  uint32_t kmax = 0;
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t key = order_key(lg[i]);
+    skey[i] = (uint16_t)key;
+    kmax = max(kmax, key);
+    atomicAdd(&sh.hist[key >> 8], 1u);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+  if (lane == 0) sh.wmax[wave] = kmax;
+  __syncthreads();
+  kmax = max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
+  const bf16_t maxbits = (kmax & 0x8000) ? (bf16_t)(kmax & 0x7fff) : (bf16_t)(~kmax & 0xffff);
+  const float vmax = bf2f(maxbits);
+  // softmax denominator over ALL entries: same partial order as sample_kernel (thread-strided
+  // partials, xor tree per wave, waves summed 0..3)
+  float se = 0.f;
+  for (int i = tid; i < n; i += 256) se += expf(bf2f(lg[i]) - vmax);
+  se = wave_sum(se);
+  if (lane == 0) sh.wsum[wave] = se;
+  if (wave == 0) wave_find_bin(sh, lane, (uint32_t)k, 0);
+  __syncthreads();
+  const float sumexp = sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3];
+  const int b1 = sh.sel[0], above1 = sh.sel[1];
+  __syncthreads();
+  sh.hist[tid] = 0;
+  __syncthreads();
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t key = skey[i];
+    if ((int)(key >> 8) == b1) atomicAdd(&sh.hist[key & 255], 1u);
+  }
+  __syncthreads();
+  if (wave == 0) wave_find_bin(sh, lane, (uint32_t)(k - above1), 2);
+  __syncthreads();
+  const uint32_t thr = ((uint32_t)b1 << 8) | (uint32_t)sh.sel[2];
+  const int c_gt = above1 + sh.sel[3];
+  const int need_eq = k - c_gt;
+
+  // ---- collect the k candidates in index order (thread chunks are contiguous index ranges)
+  int my_gt = 0, my_eq = 0;
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t key = skey[i];
+    my_gt += key > thr;
+    my_eq += key == thr;
+  }
+  int inc_gt = my_gt, inc_eq = my_eq;  // inclusive scans inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int g = __shfl_up(inc_gt, off, 64), e = __shfl_up(inc_eq, off, 64);
+    if (lane >= off) {
+      inc_gt += g;
+      inc_eq += e;
+    }
+  }
+  if (lane == 63) {
+    sh.wcnt_gt[wave] = inc_gt;
+    sh.wcnt_eq[wave] = inc_eq;
+  }
+  __syncthreads();
+  int off_gt = inc_gt - my_gt, off_eq = inc_eq - my_eq;
+  for (int w = 0; w < wave; ++w) {
+    off_gt += sh.wcnt_gt[w];
+    off_eq += sh.wcnt_eq[w];
+  }
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t key = skey[i];
+    if (key > thr) {
+      sh.cand_idx[off_gt] = i;
+      sh.cand_key[off_gt] = key;
+      ++off_gt;
+    } else if (key == thr) {
+      if (off_eq < need_eq) {
+        sh.cand_idx[c_gt + off_eq] = i;
+        sh.cand_key[c_gt + off_eq] = key;
+      }
+      ++off_eq;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+
+  // ---- wave 0: rank sort (key desc, index asc), probabilities, sequential cumsum, draws
+  {
+    const bool in = lane < k;
+    const uint32_t kc = in ? sh.cand_key[lane] : 0;
+    const int ic = in ? sh.cand_idx[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const uint32_t kj = sh.cand_key[j];
+      rank += (kj > kc) || (kj == kc && sh.cand_idx[j] < ic);
+    }
+    if (in) {
+      const bf16_t bits = (kc & 0x8000) ? (bf16_t)(kc & 0x7fff) : (bf16_t)(~kc & 0xffff);
+      sh.s_val[rank] = bf2f(bits);
+      sh.s_idx[rank] = ic;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const bool in = lane < k;
+  const float v = in ? sh.s_val[lane] : -INFINITY;
+  const int row = in ? sh.s_idx[lane] : 0;
+  const int vid = a.ids ? a.ids[row] : row;
+  const float p = in ? rbf(expf(v - vmax) / sumexp) : 0.f;
+  float run = 0.f, cum = 0.f;  // torch.cumsum on bf16: fp32 running sum in rank order, outputs rounded
+  for (int i = 0; i < k; ++i) {
+    run += __shfl(p, i, 64);
+    if (lane == i) cum = rbf(run);
+  }
+
+  int tok = small_draw(v, cum, vid, lane, k, temperature, top_p, seed, (uint32_t)slot, (uint32_t)frame, (uint32_t)draw0);
+  if (a.mode == 1) {
+    if (lane == 0) a.st.cur[(int64_t)slot * a.st.ncb1 + 1 + a.cb] = tok;
+  } else {
+    const bool second = (a.mode == 0) || (a.prev != nullptr);
+    if (second) {
+      const int tok_h = small_draw(v, cum, vid, lane, k, 1.0f, rbf(0.9f), seed, (uint32_t)slot, (uint32_t)frame,
+                                   (uint32_t)draw0 + 1);
+      if (use_ras) {
+        const int32_t* win = (a.mode == 2) ? a.prev + (int64_t)b * RAS_WIN
+                                           : a.st.window + (int64_t)slot * a.st.ncb1 * RAS_WIN;
+        bool inwin = false;
+        for (int j = 0; j < RAS_WIN; ++j) inwin |= (win[j] == tok);
+        if (inwin && tok >= a.sem_begin && tok <= a.sem_end) tok = tok_h;
+      }
+    }
+    if (a.mode == 2) {
+      if (lane == 0) a.out_tok[b] = tok;
+      return;
+    }
+    int cb0 = tok - a.sem_begin;
+    cb0 = cb0 < 0 ? 0 : (cb0 > a.cbs - 1 ? a.cbs - 1 : cb0);
+    if (lane == 0) {
+      a.st.cur[(int64_t)slot * a.st.ncb1 + 0] = tok;
+      a.st.cur[(int64_t)slot * a.st.ncb1 + 1] = cb0;
+    }
+    tok = cb0;
+  }
+  if (a.xf) {  // fast_embeddings[code] -> next fast step's input (inference.py:157,172)
+    const bf16_t* src = a.fast_emb + (int64_t)tok * a.fdim;
+    for (int c = lane * 8; c < a.fdim; c += 64 * 8)
+      *reinterpret_cast<uint4*>(a.xf + (int64_t)b * a.fdim + c) = *reinterpret_cast<const uint4*>(src + c);
+  }
+  if (a.mode == 1 && a.cb == a.st.ncb1 - 2 && lane == 0) {  // frame bookkeeping, as in sample_kernel
+    const int ncb1 = a.st.ncb1;
+    int32_t* cur = a.st.cur + (int64_t)slot * ncb1;
+    cur[ncb1 - 1] = tok;
+    if (!a.st.done[slot]) {
+      const int f = a.st.frame[slot];
+      if (f < a.st.max_frames) {
+        int32_t* o = a.st.out + ((int64_t)slot * a.st.max_frames + f) * ncb1;
+        for (int j = 0; j < ncb1; ++j) o[j] = cur[j];
+      }
+      if (f > 0) {
+        int32_t* win = a.st.window + (int64_t)slot * ncb1 * RAS_WIN;
+        for (int j = 0; j < ncb1; ++j) {
+          for (int w = 0; w < RAS_WIN - 1; ++w) win[j * RAS_WIN + w] = win[j * RAS_WIN + w + 1];
+          win[j * RAS_WIN + RAS_WIN - 1] = cur[j];
+        }
+      }
+      a.st.frame[slot] = f + 1;
+      if (f > 0) a.st.pos[slot] += 1;
+      if (cur[0] == a.im_end) a.st.done[slot] = 1;
+      else if (a.st.pos[slot] >= a.st.limit[slot] || f + 1 >= a.st.max_frames) a.st.done[slot] = 2;
+    }
+  }
+}
+
 int launch_sample(const SampleArgs& a, hipStream_t s) {
   FMI_REQUIRE(a.n >= 1 && a.n <= 65536, "sample: n=%d out of range", a.n);
+  if (a.small_k) {  // every slot draws with top_k <= 64
+    size_t smem = sizeof(SmallShared) + (size_t)a.n * 2 + 16;
+    hipLaunchKernelGGL(sample_small_kernel, dim3(a.B), dim3(256), smem, s, a);
+    FMI_CHECK_HIP(hipGetLastError());
+    return FMI_OK;
+  }
   size_t smem = sizeof(SamplerShared) + (size_t)a.n * 2 + 16;
   hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), smem, s, a);
   FMI_CHECK_HIP(hipGetLastError());

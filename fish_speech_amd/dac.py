@@ -88,6 +88,86 @@ def fold_weight_norm(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
+def expected_state_shapes(cfg: DacConfig) -> Dict[str, tuple]:
+    """Folded codec tensors (name -> shape) the loader expects: codec.pth keys after weight-norm folding
+    (SURVEY.md A.6)."""
+    s: Dict[str, tuple] = {}
+
+    def conv(p, cout, cin, k, tr=False):
+        s[p + ".conv.weight"] = (cin, cout, k) if tr else (cout, cin, k)
+        s[p + ".conv.bias"] = (cout,)
+
+    def res_unit(p, d):
+        s[p + ".block.0.alpha"] = (1, d, 1)
+        conv(p + ".block.1", d, d, 7)
+        s[p + ".block.2.alpha"] = (1, d, 1)
+        conv(p + ".block.3", d, d, 1)
+
+    def tf(p, d, n, ffn):
+        for i in range(n):
+            l = f"{p}.layers.{i}"
+            s[l + ".attention.wqkv.weight"] = (3 * d, d)
+            s[l + ".attention.wo.weight"] = (d, d)
+            s[l + ".feed_forward.w1.weight"] = (ffn, d)
+            s[l + ".feed_forward.w3.weight"] = (ffn, d)
+            s[l + ".feed_forward.w2.weight"] = (d, ffn)
+            for n2 in ("ffn_norm.weight", "attention_norm.weight", "attention_layer_scale.gamma", "ffn_layer_scale.gamma"):
+                s[f"{l}.{n2}"] = (d,)
+        s[p + ".norm.weight"] = (d,)
+
+    d = cfg.encoder_dim
+    conv("encoder.block.0", d, 1, 7)
+    for bi, stride in enumerate(cfg.encoder_rates):
+        d *= 2
+        p = f"encoder.block.{bi + 1}"
+        for r in range(3):
+            res_unit(f"{p}.block.{r}", d // 2)
+        s[f"{p}.block.3.alpha"] = (1, d // 2, 1)
+        conv(f"{p}.block.4", d, d // 2, 2 * stride)
+        if bi == len(cfg.encoder_rates) - 1 and cfg.enc_tf_layers:
+            tf(f"{p}.block.5", d, cfg.enc_tf_layers, 3 * d)
+    s["encoder.block.5.alpha"] = (1, d, 1)
+    L = cfg.latent_dim
+    conv("encoder.block.6", L, d, 3)
+    for name, n, size in (("semantic_quantizer", 1, cfg.semantic_codebook_size), ("quantizer", cfg.n_codebooks, cfg.codebook_size)):
+        for i in range(n):
+            p = f"quantizer.{name}.quantizers.{i}"
+            s[p + ".in_proj.weight"] = (cfg.codebook_dim, L, 1)
+            s[p + ".in_proj.bias"] = (cfg.codebook_dim,)
+            s[p + ".out_proj.weight"] = (L, cfg.codebook_dim, 1)
+            s[p + ".out_proj.bias"] = (L,)
+            s[p + ".codebook.weight"] = (size, cfg.codebook_dim)
+    for name in ("downsample", "upsample"):
+        for i in range(len(cfg.downsample)):
+            p = f"quantizer.{name}.{i}"
+            fac = cfg.downsample[i] if name == "downsample" else list(reversed(cfg.downsample))[i]
+            s[p + ".0.conv.weight"] = (L, L, fac)
+            s[p + ".0.conv.bias"] = (L,)
+            s[p + ".1.gamma"] = (L,)
+            s[p + ".1.dwconv.conv.weight"] = (L, 1, 7)
+            s[p + ".1.dwconv.conv.bias"] = (L,)
+            s[p + ".1.norm.weight"] = (L,)
+            s[p + ".1.norm.bias"] = (L,)
+            s[p + ".1.pwconv1.weight"] = (4 * L, L)
+            s[p + ".1.pwconv1.bias"] = (4 * L,)
+            s[p + ".1.pwconv2.weight"] = (L, 4 * L)
+            s[p + ".1.pwconv2.bias"] = (L,)
+    for name in ("pre_module", "post_module"):
+        tf(f"quantizer.{name}", L, cfg.tf_layers, L * cfg.tf_ffn_mult)
+    conv("decoder.model.0", cfg.decoder_dim, L, 7)
+    for i, stride in enumerate(cfg.decoder_rates):
+        cin, cout = cfg.decoder_dim // 2 ** i, cfg.decoder_dim // 2 ** (i + 1)
+        p = f"decoder.model.{i + 1}"
+        s[p + ".block.0.alpha"] = (1, cin, 1)
+        conv(p + ".block.1", cout, cin, 2 * stride, tr=True)
+        for r in range(3):
+            res_unit(f"{p}.block.{2 + r}", cout)
+    cl = cfg.decoder_dim // 2 ** len(cfg.decoder_rates)
+    s["decoder.model.5.alpha"] = (1, cl, 1)
+    conv("decoder.model.6", 1, cl, 7)
+    return s
+
+
 def _rope_table(n_pos: int, n_elem: int = 64, base: float = 10000.0) -> torch.Tensor:
     """modded_dac.py:442-452 (bf16 by default), built with torch so the table is the reference's."""
     freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
@@ -143,7 +223,10 @@ class MiDAC:
             state = state["state_dict"]
         if any("generator" in k for k in state):
             state = {k.replace("generator.", ""): v for k, v in state.items() if "generator." in k}
-        folded = fold_weight_norm(state)
+        return self.load_folded_state(fold_weight_norm(state), strict=strict)
+
+    def load_folded_state(self, folded: Dict[str, torch.Tensor], strict: bool = True):
+        """Plain (already weight-norm-folded) tensors by name; see expected_state_shapes()."""
         s = self._stream()
         for name, t in folded.items():
             t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()

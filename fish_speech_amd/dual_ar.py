@@ -364,6 +364,15 @@ class MiDualAR:
         t = torch.frombuffer(buf, dtype=torch.int32)[: n.value * ncb1].reshape(n.value, ncb1).clone()
         return t, done.value
 
+    def frames_device(self, n_slots: int, n_frames: int) -> torch.Tensor:
+        """Device view of the frames generated so far: (n_slots, n_frames, 1+ncb) int32 (slots 0..n-1)."""
+        p, mf = C.c_void_p(), C.c_int()
+        check(self.lib.fmi_dualar_out_ptr(self._h, C.byref(p), C.byref(mf)))
+        ncb1 = self.config.num_codebooks + 1
+        full = _from_ptr(p.value, (self.max_batch_size, mf.value, ncb1), torch.int32, self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        return full[:n_slots, :n_frames]
+
     def release(self, slot: int):
         check(self.lib.fmi_dualar_release(self._h, int(slot)))
 
@@ -508,3 +517,28 @@ def generate_batch(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_
         outs.append(seq.to(p.dtype) if p.dtype in (torch.int32, torch.int64) else seq)
         model.release(i)
     return outs
+
+
+@torch.no_grad()
+def generate_batch_device(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_tokens: int,
+                          seeds: Optional[Sequence[int]] = None, temperature: float = 1.0, top_p: float = 0.9,
+                          top_k: int = 30, use_ras: bool = True) -> torch.Tensor:
+    """Fixed-length batch generation whose result stays on the device: returns the codebook rows
+    (B, num_codebooks, max_new_tokens) int64, ready for ``MiDAC.from_indices`` -- no host round trip
+    between the Dual-AR loop and the codec.  Every slot runs exactly ``max_new_tokens`` frames
+    (use ``model.set_ignore_eos(True)``), so this is the serving/benchmark path for known lengths."""
+    cfg = model.config
+    n = len(prompts)
+    if not model._cache_setup_done:
+        model.setup_caches(max_batch_size=n, max_seq_len=cfg.max_seq_len)
+    slots = list(range(n))
+    seeds = list(seeds) if seeds is not None else [model.next_seed() for _ in range(n)]
+    samp = [model._sampling(temperature, top_p, top_k, seeds[i], use_ras) for i in range(n)]
+    model.prefill(slots, prompts, [max_new_tokens] * n, samp)
+    if max_new_tokens > 1:
+        model.decode(slots, max_new_tokens - 1)
+    out = model.frames_device(n, max_new_tokens)          # (B, frames, 1+ncb) int32 view
+    codes = out[:, :, 1:].permute(0, 2, 1).to(torch.int64).contiguous()
+    for i in slots:
+        model.release(i)
+    return codes

@@ -105,6 +105,9 @@ int fmi_dualar_read(fmi_dualar* h, int slot, int32_t* out_host, int max_frames, 
 int fmi_dualar_poll_done(fmi_dualar* h, int n, const int32_t* slot_ids, int32_t* done_host,
                          void* stream);
 int fmi_dualar_release(fmi_dualar* h, int slot);
+/* Device pointer of the generated-frames buffer, int32 [max_batch][max_frames][1+num_codebooks]
+ * (slot-major), so that a consumer on the same GPU (the codec) reads the codes without a host copy. */
+int fmi_dualar_out_ptr(fmi_dualar* h, void** out_dev, int* max_frames);
 
 /* Drop-in single-step seam = the `decode_one_token` callable
  * (decode_one_token_ar, inference.py:96-181) for slot 0 semantics of the reference
