@@ -121,10 +121,12 @@ def run_step(model, codec, prompts, samp_seeds, device):
     return codes, wav
 
 
-def cpu_baseline(cfg, state_dev, n_frames=6):
-    """The oracle (a CPU restatement of the reference path, kind 'port') timed on this box's host
-    cores on a bounded sample: prefill of one 200-token prompt + n_frames decode frames, batch 1 (the
-    reference cannot batch)."""
+def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=5, codec_frames=32):
+    """The oracle (CPU restatement of the reference path, kind 'port') timed on this box's host cores on a
+    bounded sample: Dual-AR prefill of one 200-token prompt + n_frames decode frames (batch 1 -- the
+    reference cannot batch), and codec decode of codec_frames frames; both extrapolated linearly to one
+    10 s utterance."""
+    from oracle import dac as OD
     from oracle import dual_ar as O
 
     oc = O.s2_pro_shaped_config(max_seq_len=512)
@@ -132,20 +134,33 @@ def cpu_baseline(cfg, state_dev, n_frames=6):
     st = {k: v.cpu() for k, v in state_dev.items()}
     orc = O.DualAROracle(oc, st)
     prompt = make_prompts(cfg, 1, 1000)[0]
-    t0 = time.perf_counter()
     orc.setup_caches(1, oc.max_seq_len)
-    y = O.generate(orc, prompt, 1, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
+    t0 = time.perf_counter()
+    O.generate(orc, prompt, 1, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
     t_prefill = time.perf_counter() - t0
     t0 = time.perf_counter()
-    orc2_frames = n_frames
-    y = O.generate(orc, prompt, 1 + orc2_frames, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
+    O.generate(orc, prompt, 1 + n_frames, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
     t_all = time.perf_counter() - t0
-    per_frame = max(t_all - t_prefill, 1e-9) / orc2_frames
-    t_utt = t_prefill + (N_FRAMES - 1) * per_frame
+    per_frame = max(t_all - t_prefill, 1e-9) / n_frames
+    t_ar = t_prefill + (N_FRAMES - 1) * per_frame
+    del orc, st
+    t_codec, note = 0.0, "codec not included"
+    if codec_state_dev is not None:
+        ccfg = OD.DacConfig()
+        cst = {k: v.float().cpu() for k, v in codec_state_dev.items()}
+        corc = OD.DacOracle(ccfg, cst)
+        codes = OD.make_codes(ccfg, 1, codec_frames, seed=1)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            corc.from_indices(codes)
+            t_c = time.perf_counter() - t0
+        t_codec = t_c * N_FRAMES / codec_frames
+        note = f"codec decode {codec_frames} frames {t_c:.2f}s (fp32)"
     return {
-        "value": round(10.0 / t_utt, 5), "unit": "audio-sec/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"oracle (torch CPU bf16, batch 1): prefill {PROMPT_T} tokens {t_prefill:.2f}s + {orc2_frames} "
-                  f"decode frames at {per_frame:.3f}s/frame, extrapolated to {N_FRAMES} frames; codec not included",
+        "value": round(10.0 / (t_ar + t_codec), 5), "unit": "audio-sec/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle on torch CPU, batch 1: prefill {PROMPT_T} tokens {t_prefill:.2f}s + {n_frames} decode "
+                  f"frames at {per_frame:.3f}s/frame (bf16); {note}; extrapolated to one {N_FRAMES}-frame utterance",
     }
 
 
@@ -190,14 +205,15 @@ def main():
         broadcast_arena(model, src=0)
     model.setup_caches(BATCH, PROMPT_T + N_FRAMES + 8)
     model.set_ignore_eos(True)
-    codec = None
+    codec, codec_state = None, None
     if not args.no_codec:
         from fish_speech_amd.dac import DacConfig, MiDAC
 
         ccfg = DacConfig()
         codec = MiDAC(ccfg, device=device)
         if rank == 0:
-            codec.load_folded_state(synthetic_codec_state(ccfg, device))
+            codec_state = synthetic_codec_state(ccfg, device)
+            codec.load_folded_state(codec_state)
         if world > 1:
             from fish_speech_amd.dist import broadcast_arena
 
@@ -267,7 +283,7 @@ def main():
                      "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, state)
+        out["cpu_baseline"] = cpu_baseline(cfg, state, codec_state)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:
