@@ -121,6 +121,7 @@ struct SampleArgs {
   const int32_t* prev;    // [B][RAS_WIN] or nullptr
   int32_t* out_tok;       // [B]
   int small_k;            // 1 = every slot uses top_k <= 64 (fast single-wave finish)
+  int dbg_stop;           // profiling only: return after stage N of sample_small_kernel (0 = run all)
 };
 int launch_sample(const SampleArgs& a, hipStream_t s);
 

@@ -660,8 +660,8 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 //            lane; token `pos` comes from LDS.  Online softmax per lane group, merged in-wave by
 //            shuffles, across waves through LDS.
 template <int D, int G>
-__global__ __launch_bounds__(1024) void attn_decode_fused_kernel(AttnArgs a) {
-  constexpr int NW = 16, LPT = D / 8, TPW = 64 / LPT, UN = 4;
+__global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
+  constexpr int NW = 8, LPT = D / 8, TPW = 64 / LPT, UN = 4;
   __shared__ float s_q[G][D];
   __shared__ float s_k[D], s_v[D];
   __shared__ float s_m[NW][G], s_l[NW][G];
@@ -673,6 +673,26 @@ __global__ __launch_bounds__(1024) void attn_decode_fused_kernel(AttnArgs a) {
   const int H = a.H, KVH = a.KVH;
   const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
   const bf16_t* src = a.qkv + (int64_t)r * (H + 2 * KVH) * D;
+
+  // ---- prefetch: the first trip of cached K/V rows does not depend on q, so it is issued before the
+  // norm/RoPE phase and its HBM latency overlaps that phase
+  const int sub = lane / LPT, dl = lane % LPT;
+  const int n_groups = (pos + TPW - 1) / TPW;
+  uint4 kv[UN], vv[UN];
+  bool valid[UN];
+  auto load_trip = [&](int g0) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int t = (g0 + u * NW) * TPW + sub;
+      valid[u] = t < pos;
+      const int tc = valid[u] ? t : 0;
+      const int page = bt[tc / KV_PAGE];
+      const int64_t base = (((int64_t)page * KVH + kvh) * KV_PAGE + (tc % KV_PAGE)) * D + dl * 8;
+      kv[u] = *reinterpret_cast<const uint4*>(a.kpool + base);
+      vv[u] = *reinterpret_cast<const uint4*>(a.vpool + base);
+    }
+  };
+  if (wave < n_groups) load_trip(wave);
 
   // ---- phase 1
   for (int item = wave; item < G + 2; item += NW) {
@@ -714,7 +734,6 @@ __global__ __launch_bounds__(1024) void attn_decode_fused_kernel(AttnArgs a) {
   __syncthreads();
 
   // ---- phase 2
-  const int sub = lane / LPT, dl = lane % LPT;
   const float scale = 1.0f / sqrtf((float)D);
   float q[G][8];
 #pragma unroll
@@ -752,32 +771,23 @@ __global__ __launch_bounds__(1024) void attn_decode_fused_kernel(AttnArgs a) {
   };
 
   // cached tokens [0, pos): wave w takes token groups w, w+NW, ... of TPW tokens; UN groups per trip
-  const int n_groups = (pos + TPW - 1) / TPW;
   for (int g0 = wave; g0 < n_groups; g0 += NW * UN) {
-    uint4 kv[UN], vv[UN];
-    bool valid[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int t = (g0 + u * NW) * TPW + sub;
-      valid[u] = t < pos;
-      const int tc = valid[u] ? t : 0;
-      const int page = bt[tc / KV_PAGE];
-      const int64_t base = (((int64_t)page * KVH + kvh) * KV_PAGE + (tc % KV_PAGE)) * D + dl * 8;
-      kv[u] = *reinterpret_cast<const uint4*>(a.kpool + base);
-      vv[u] = *reinterpret_cast<const uint4*>(a.vpool + base);
-    }
+    float kf[UN][8], vf[UN][8];
+    bool vld[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const bf16_t* ke = reinterpret_cast<const bf16_t*>(&kv[u]);
       const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv[u]);
-      float kf[8], vf[8];
+      vld[u] = valid[u];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        kf[j] = bf2f(ke[j]);
-        vf[j] = bf2f(ve[j]);
+        kf[u][j] = bf2f(ke[j]);
+        vf[u][j] = bf2f(ve[j]);
       }
-      consume(kf, vf, valid[u]);
     }
+    if (g0 + NW * UN < n_groups) load_trip(g0 + NW * UN);  // next trip in flight during the maths
+#pragma unroll
+    for (int u = 0; u < UN; ++u) consume(kf[u], vf[u], vld[u]);
   }
   if (wave == 0) {  // the current token, straight from LDS (lane group 0 only)
     float kf[8], vf[8];
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(1024) void attn_decode_fused_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < G * D; o += 1024) {
+  for (int o = threadIdx.x; o < G * D; o += 512) {
     const int gq = o / D, d = o % D;
     float M = -1e30f;
 #pragma unroll
@@ -837,7 +847,7 @@ __global__ __launch_bounds__(1024) void attn_decode_fused_kernel(AttnArgs a) {
 template <int D>
 static int launch_attn_decode_d(const AttnArgs& a, hipStream_t s) {
   const int G = a.H / a.KVH;
-  dim3 grid(a.rows, a.KVH), block(1024);
+  dim3 grid(a.rows, a.KVH), block(512);
   switch (G) {
     case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 1>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 2>), grid, block, 0, s, a); break;
@@ -1381,6 +1391,10 @@ __device__ inline int small_draw(float v, float cum, int vid, int lane, int k, f
   return (best > 0.f) ? best_id : 0;  // all-zero race -> the reference's argmax lands on index 0
 }
 
+constexpr int SMALL_EPT = 17;  // keys per thread held in registers: n <= 256 * 17 = 4352
+
+__device__ inline float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   SmallShared& sh = *reinterpret_cast<SmallShared*>(smem_raw);
@@ -1405,18 +1419,21 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   int k = top_k < n ? top_k : n;
   if (k > 64) k = 64;
   if (k < 1) k = 1;
+  if (a.dbg_stop == 1) return;
 
-  // ---- pass 1 (all waves): keys, max, high-byte histogram
-  sh.hist[tid] = 0;
-  __syncthreads();
-  const int ept = (n + 255) / 256;
-  const int i0 = tid * ept, i1 = min(n, i0 + ept);
+  // ---- pass 1: coalesced loads (element tid + 256 j), keys to LDS, block max
+  float xv[SMALL_EPT];
   uint32_t kmax = 0;
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t key = order_key(lg[i]);
-    skey[i] = (uint16_t)key;
-    kmax = max(kmax, key);
-    atomicAdd(&sh.hist[key >> 8], 1u);
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j) {
+    const int i = tid + 256 * j;
+    const bf16_t raw = i < n ? lg[i] : (bf16_t)0xff80;  // -inf padding
+    xv[j] = bf2f(raw);
+    const uint32_t key = order_key(raw);
+    if (i < n) {
+      skey[i] = (uint16_t)key;
+      kmax = max(kmax, key);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
@@ -1425,38 +1442,75 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   kmax = max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
   const bf16_t maxbits = (kmax & 0x8000) ? (bf16_t)(kmax & 0x7fff) : (bf16_t)(~kmax & 0xffff);
   const float vmax = bf2f(maxbits);
-  // softmax denominator over ALL entries: same partial order as sample_kernel (thread-strided
-  // partials, xor tree per wave, waves summed 0..3)
+  if (a.dbg_stop == 2) return;
+  // softmax denominator over ALL entries, same summation order as sample_kernel (thread-strided
+  // partials j = 0.., xor tree per wave, waves summed 0..3)
   float se = 0.f;
-  for (int i = tid; i < n; i += 256) se += expf(bf2f(lg[i]) - vmax);
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j)
+    if (tid + 256 * j < n) se += expf(xv[j] - vmax);
   se = wave_sum(se);
   if (lane == 0) sh.wsum[wave] = se;
-  if (wave == 0) wave_find_bin(sh, lane, (uint32_t)k, 0);
+  // this thread's CONTIGUOUS chunk of keys into registers (index order matters for ties)
+  const int ept = (n + 255) / 256;
+  const int i0 = tid * ept;
+  uint32_t kr[SMALL_EPT];
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j) kr[j] = (j < ept && i0 + j < n) ? (uint32_t)skey[i0 + j] : 0u;
+  // (key 0 never occurs for a real entry: order_key(x) >= 0x007f for -inf and above)
   __syncthreads();
   const float sumexp = sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3];
-  const int b1 = sh.sel[0], above1 = sh.sel[1];
-  __syncthreads();
-  sh.hist[tid] = 0;
-  __syncthreads();
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t key = skey[i];
-    if ((int)(key >> 8) == b1) atomicAdd(&sh.hist[key & 255], 1u);
-  }
-  __syncthreads();
-  if (wave == 0) wave_find_bin(sh, lane, (uint32_t)(k - above1), 2);
-  __syncthreads();
-  const uint32_t thr = ((uint32_t)b1 << 8) | (uint32_t)sh.sel[2];
-  const int c_gt = above1 + sh.sel[3];
-  const int need_eq = k - c_gt;
+  if (a.dbg_stop == 3) return;
 
-  // ---- collect the k candidates in index order (thread chunks are contiguous index ranges)
-  int my_gt = 0, my_eq = 0;
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t key = skey[i];
-    my_gt += key > thr;
-    my_eq += key == thr;
+  // ---- k-th largest key: radix-4 descent over the 16 key bits, counts from registers
+  // thr = max T with count(key >= T) >= k
+  uint32_t thr = 0;
+#pragma unroll 1
+  for (int step = 0; step < 8; ++step) {
+    const int sh_bits = 14 - 2 * step;
+    const uint32_t c1 = thr | (1u << sh_bits), c2 = thr | (2u << sh_bits), c3 = thr | (3u << sh_bits);
+    int n1 = 0, n2 = 0, n3 = 0;
+#pragma unroll
+    for (int j = 0; j < SMALL_EPT; ++j) {
+      n1 += kr[j] >= c1;
+      n2 += kr[j] >= c2;
+      n3 += kr[j] >= c3;
+    }
+    int packed = n1 | (n2 << 10);  // each count <= 17 per thread, <= 1088 per wave: 10 bits are not enough
+    // (pack only two 16-bit fields)
+    packed = n1 | (n2 << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      packed += __shfl_xor(packed, o, 64);
+      n3 += __shfl_xor(n3, o, 64);
+    }
+    const int par = step & 1;
+    if (lane == 0) {
+      sh.hist[par * 16 + wave * 2] = (uint32_t)packed;
+      sh.hist[par * 16 + wave * 2 + 1] = (uint32_t)n3;
+    }
+    __syncthreads();
+    uint32_t tp = 0, t3 = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      tp += sh.hist[par * 16 + w * 2];
+      t3 += sh.hist[par * 16 + w * 2 + 1];
+    }
+    const uint32_t t1 = tp & 0xffff, t2 = tp >> 16;
+    if (t3 >= (uint32_t)k) thr = c3;
+    else if (t2 >= (uint32_t)k) thr = c2;
+    else if (t1 >= (uint32_t)k) thr = c1;
   }
-  int inc_gt = my_gt, inc_eq = my_eq;  // inclusive scans inside the wave
+  int my_gt = 0, my_eq = 0;
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j) {
+    my_gt += kr[j] > thr;
+    my_eq += (kr[j] == thr) && (thr != 0);
+  }
+  if (a.dbg_stop == 4) return;
+
+  // ---- collect the k candidates in index order
+  int inc_gt = my_gt, inc_eq = my_eq;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int g = __shfl_up(inc_gt, off, 64), e = __shfl_up(inc_eq, off, 64);
@@ -1475,54 +1529,61 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     off_gt += sh.wcnt_gt[w];
     off_eq += sh.wcnt_eq[w];
   }
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t key = skey[i];
+  const int c_gt = sh.wcnt_gt[0] + sh.wcnt_gt[1] + sh.wcnt_gt[2] + sh.wcnt_gt[3];
+  const int need_eq = k - c_gt;
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j) {
+    const uint32_t key = kr[j];
     if (key > thr) {
-      sh.cand_idx[off_gt] = i;
+      sh.cand_idx[off_gt] = i0 + j;
       sh.cand_key[off_gt] = key;
       ++off_gt;
-    } else if (key == thr) {
+    } else if (key == thr && thr != 0) {
       if (off_eq < need_eq) {
-        sh.cand_idx[c_gt + off_eq] = i;
+        sh.cand_idx[c_gt + off_eq] = i0 + j;
         sh.cand_key[c_gt + off_eq] = key;
       }
       ++off_eq;
     }
   }
   __syncthreads();
-  if (wave != 0) return;
+  if (wave != 0 || a.dbg_stop == 5) return;
 
-  // ---- wave 0: rank sort (key desc, index asc), probabilities, sequential cumsum, draws
-  {
-    const bool in = lane < k;
-    const uint32_t kc = in ? sh.cand_key[lane] : 0;
-    const int ic = in ? sh.cand_idx[lane] : 0x7fffffff;
-    int rank = 0;
-    for (int j = 0; j < k; ++j) {
-      const uint32_t kj = sh.cand_key[j];
-      rank += (kj > kc) || (kj == kc && sh.cand_idx[j] < ic);
-    }
-    if (in) {
-      const bf16_t bits = (kc & 0x8000) ? (bf16_t)(kc & 0x7fff) : (bf16_t)(~kc & 0xffff);
-      sh.s_val[rank] = bf2f(bits);
-      sh.s_idx[rank] = ic;
-    }
+  // ---- wave 0: rank sort (key desc, index asc) with scalar broadcasts, sequential cumsum
+  const bool in = lane < k;
+  const uint32_t kc = in ? sh.cand_key[lane] : 0;
+  const int ic = in ? sh.cand_idx[lane] : 0x7fffffff;
+  int rank = 0;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kc, j);
+    const int ij = __builtin_amdgcn_readlane(ic, j);
+    rank += (j < k) && ((kj > kc) || (kj == kc && ij < ic));
+  }
+  // permute (value, row) into rank order: lane r receives the candidate whose rank is r
+  if (in) {
+    sh.s_val[rank] = __uint_as_float(kc);
+    sh.s_idx[rank] = ic;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const bool in = lane < k;
-  const float v = in ? sh.s_val[lane] : -INFINITY;
+  const uint32_t ks = in ? __float_as_uint(sh.s_val[lane]) : 0;
+  const bf16_t vbits = (ks & 0x8000) ? (bf16_t)(ks & 0x7fff) : (bf16_t)(~ks & 0xffff);
+  const float v = in ? bf2f(vbits) : -INFINITY;
   const int row = in ? sh.s_idx[lane] : 0;
   const int vid = a.ids ? a.ids[row] : row;
   const float p = in ? rbf(expf(v - vmax) / sumexp) : 0.f;
   float run = 0.f, cum = 0.f;  // torch.cumsum on bf16: fp32 running sum in rank order, outputs rounded
-  for (int i = 0; i < k; ++i) {
-    run += __shfl(p, i, 64);
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    run += rl_f(p, i);  // lanes >= k hold 0
     if (lane == i) cum = rbf(run);
   }
 
+  if (a.dbg_stop == 6) return;
   int tok = small_draw(v, cum, vid, lane, k, temperature, top_p, seed, (uint32_t)slot, (uint32_t)frame, (uint32_t)draw0);
+  if (a.dbg_stop == 7) return;
   if (a.mode == 1) {
     if (lane == 0) a.st.cur[(int64_t)slot * a.st.ncb1 + 1 + a.cb] = tok;
   } else {
@@ -1582,7 +1643,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
 
 int launch_sample(const SampleArgs& a, hipStream_t s) {
   FMI_REQUIRE(a.n >= 1 && a.n <= 65536, "sample: n=%d out of range", a.n);
-  if (a.small_k) {  // every slot draws with top_k <= 64
+  if (a.small_k && a.n <= 256 * SMALL_EPT) {  // every slot draws with top_k <= 64, keys fit in registers
     size_t smem = sizeof(SmallShared) + (size_t)a.n * 2 + 16;
     hipLaunchKernelGGL(sample_small_kernel, dim3(a.B), dim3(256), smem, s, a);
     FMI_CHECK_HIP(hipGetLastError());

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-frame HBM read traffic of the decode frame from a rocprofv3 `--pmc FETCH_SIZE --kernel-trace
+--output-format csv` pass (collected separately from the timing runs, as MI355X_MICROARCH.md prescribes).
+FETCH_SIZE is in KiB and, on gfx950, reports exactly half of the bytes of wide coalesced streaming reads,
+so it is doubled.  usage: python tools/pmc_traffic.py <counter_collection.csv> <n_frames_of_that_run>"""
+import collections
+import csv
+import sys
+
+
+def main(path, n_frames):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != "FETCH_SIZE" or "fmi::" not in r["Kernel_Name"]:
+            continue
+        k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"]) * 1024 * 2
+    n_decode = n_frames - 1
+    print(f"# {path}: {n_frames} frames (1 prefill frame + {n_decode} graph-replayed decode frames)")
+    print(f"{'calls':>7} {'avg MB/launch':>14}  kernel [work-groups]")
+    frame_bytes = 0.0
+    for (name, wgs), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{n:7d} {v / n / 1e6:14.3f}  {name} [{wgs}]")
+        decode_kernel = any(t in name for t in ("linear_skinny", "attn_decode_fused", "fast_attn", "sample", "embed", "rmsnorm_rows"))
+        if decode_kernel:
+            frame_bytes += v
+    # the prefill frame runs the same tail (fast chain + heads) once; slow layers there use the tiled path
+    print(f"\nHBM bytes fetched by the decode-frame kernels: {frame_bytes / 1e9:.3f} GB over the run "
+          f"= {frame_bytes / (n_decode + 0.52) / 1e9:.3f} GB per decode frame "
+          f"(prefill-frame tail counted as 0.52 frame: 8.07+0.19 of 15.55 GB)")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]))
