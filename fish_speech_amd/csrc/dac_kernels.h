@@ -32,6 +32,7 @@ struct ConvArgs {
   int tap_base;         // input column of tap 0 for output column 0 (= -(left pad); 0 for transposed)
   int out_stride;       // output column step per computed column (1; stride for transposed)
   int act;
+  int dbg;              // profiling only: 1 = skip LDS staging, 2 = skip MFMAs, 3 = skip Snake
 };
 // out[b][co][q*out_stride + phase] = res + gamma * act(bias + sum_ci sum_tap w[phase][tap][ci][co] *
 //                                    snake(x)[b][ci][q*x_stride + tap_base + tap*tap_step])

@@ -13,6 +13,8 @@
 // and transposed convolutions and all linear layers (k = 1): M = output channels, N = time,
 // reduction = input channels x taps; input tile (with fused Snake) and weight tile are staged
 // through LDS, 8 input channels at a time.
+#include <stdlib.h>
+
 #include "dac_kernels.h"
 
 namespace fmi {
@@ -94,21 +96,31 @@ __device__ inline float snake_f(float v, float alpha) {
 
 __device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-constexpr int CONV_CI = 8;  // input channels staged per step
+// CI input channels are staged per step (8 for multi-tap convs, 32 for k = 1 where a step holds
+// almost no math).  Staging was the bottleneck of the first version (ablation in profiles/): so
+//   * the weight tile goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction
+//     moves 1 KiB, no VGPR round trip, no VALU); the packed layout [tap][ci][co_pad] makes every tile
+//     row contiguous, the LDS image is the lane-linear copy the DMA requires;
+//   * the input tile is staged with division-free indexing: a wave owns whole channel rows, lanes run
+//     along time (coalesced), Snake is applied on the way into LDS.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int MT, int NT>
+template <int MT, int NT, int CI, bool DMA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
-  float* Xs = smem;                    // [CONV_CI][wx]
-  float* Ws = smem + CONV_CI * wx;     // [taps][CONV_CI][CO_T]
+  constexpr int ROWB = CO_T * 4;  // bytes per weight-tile row
+  float* Ws = smem;                        // [taps][CI][CO_T]  (first: 16-byte aligned for the DMA)
+  const int taps = a.w.taps;
+  const int nw = taps * CI * CO_T;
+  float* Xs = smem + nw;                   // [CI][wx]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lk = lane >> 5;
   const int q0 = blockIdx.x * TT;
   const int co0 = blockIdx.y * CO_T;
   const int b = blockIdx.z / a.w.phases, phase = blockIdx.z % a.w.phases;
-  const int taps = a.w.taps;
   const int c0 = q0 * a.x_stride + a.tap_base - tap_off0;  // input column of LDS column 0
   const float* xb = a.x + (int64_t)b * a.w.cin * a.lin;
   const float* wph = a.w.w + (int64_t)phase * taps * a.w.cin_pad * a.w.cout_pad;
@@ -122,37 +134,55 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, i
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int qw = wave * NT * 32;  // this wave's first column inside the tile
+  const int n_pieces = nw / 256;  // 1 KiB pieces of the weight tile (CI*CO_T*4 is a multiple of 1 KiB)
 
-  for (int ci0 = 0; ci0 < a.w.cin_pad; ci0 += CONV_CI) {
-    // ---- stage the input tile (Snake fused) and the weight tile
-    for (int e = tid; e < CONV_CI * wx; e += 256) {
-      const int r = e / wx, c = e - r * wx;
-      const int ci = ci0 + r, col = c0 + c;
-      float v = 0.f;
-      if (ci < a.w.cin && col >= 0 && col < a.lin) {
-        v = xb[(int64_t)ci * a.lin + col];
-        if (a.snake_alpha) v = snake_f(v, a.snake_alpha[ci]);
+  for (int ci0 = 0; ci0 < a.w.cin_pad; ci0 += CI) {
+    // ---- weight tile
+    if (DMA) {
+      for (int p = wave; p < n_pieces; p += 4) {
+        const int o = p * 1024 + lane * 16;         // byte offset inside the tile == inside LDS
+        const int row = o / ROWB, cb = o - row * ROWB;  // row = tap * CI + r
+        const int tp = row / CI, r = row - tp * CI;
+        const char* g = reinterpret_cast<const char*>(wph + ((int64_t)tp * a.w.cin_pad + ci0 + r) * a.w.cout_pad + co0) + cb;
+        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(reinterpret_cast<char*>(Ws) + p * 1024), 16, 0, 0);
       }
-      Xs[e] = v;
+    } else {
+      for (int e = tid; e < nw; e += 256) {
+        const int i = e % CO_T, r = (e / CO_T) % CI, tp = e / (CO_T * CI);
+        float v = 0.f;
+        if (co0 + i < a.w.cout_pad) v = wph[((int64_t)tp * a.w.cin_pad + ci0 + r) * a.w.cout_pad + co0 + i];
+        Ws[e] = v;
+      }
     }
-    for (int e = tid; e < taps * CONV_CI * CO_T; e += 256) {
-      const int i = e % CO_T;
-      const int r = (e / CO_T) % CONV_CI;
-      const int tp = e / (CO_T * CONV_CI);
-      float v = 0.f;
-      if (co0 + i < a.w.cout_pad) v = wph[((int64_t)tp * a.w.cin_pad + ci0 + r) * a.w.cout_pad + co0 + i];
-      Ws[e] = v;
+    // ---- input tile (Snake fused): wave w stages rows w, w+4, ...; lanes along time
+    if (a.dbg != 1) {
+      for (int r = wave; r < CI; r += 4) {
+        const int ci = ci0 + r;
+        const bool crow = ci < a.w.cin;
+        const float* xr = xb + (int64_t)(crow ? ci : 0) * a.lin;
+        const float alpha = (crow && a.snake_alpha && a.dbg != 3) ? a.snake_alpha[ci] : 0.f;
+        const bool do_snake = a.snake_alpha && a.dbg != 3;
+        for (int c = lane; c < wx; c += 64) {
+          const int col = c0 + c;
+          float v = 0.f;
+          if (crow && col >= 0 && col < a.lin) {
+            v = xr[col];
+            if (do_snake) v = snake_f(v, alpha);
+          }
+          Xs[r * wx + c] = v;
+        }
+      }
     }
-    __syncthreads();
+    __syncthreads();  // also drains the LDS-DMA (vmcnt(0) is part of the barrier's fence)
     // ---- multiply: reduction index = (tap, channel pair)
-    for (int tp = 0; tp < taps; ++tp) {
+    for (int tp = 0; tp < (a.dbg == 2 ? 0 : taps); ++tp) {
       const int xoff = tap_off0 + tp * a.tap_step;
 #pragma unroll
-      for (int k2 = 0; k2 < CONV_CI / 2; ++k2) {
+      for (int k2 = 0; k2 < CI / 2; ++k2) {
         const int row = k2 * 2 + lk;
         float af[MT], bf[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = Ws[(tp * CONV_CI + row) * CO_T + i * 32 + li];
+        for (int i = 0; i < MT; ++i) af[i] = Ws[(tp * CI + row) * CO_T + i * 32 + li];
 #pragma unroll
         for (int j = 0; j < NT; ++j) bf[j] = Xs[row * wx + (qw + j * 32 + li) * a.x_stride + xoff];
 #pragma unroll
@@ -189,37 +219,58 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, i
     }
 }
 
+template <int MT, int NT, int CI>
+static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
+  const ConvW& w = a.w;
+  constexpr int TT = 4 * NT * 32, CO_T = MT * 32;
+  const int wx = (TT - 1) * a.x_stride + span;
+  const size_t smem = (size_t)(CI * wx + w.taps * CI * CO_T) * sizeof(float);
+  FMI_REQUIRE(smem <= 160 * 1024, "conv: LDS tile of %zu bytes exceeds 160 KiB", smem);
+  static const bool allow_dma = []() { const char* e = getenv("FMI_CONV_DMA"); return !(e && e[0] == '0'); }();
+  // the DMA copies whole CO_T-wide rows: every tile must lie inside the padded weight rows
+  const bool dma = allow_dma && (w.cout_pad % CO_T == 0) && (w.cin_pad % CI == 0);
+  dim3 grid(cdiv(ncols, TT), cdiv(w.cout_pad, CO_T), a.B * w.phases), block(256);
+  if (dma) {
+    if (smem > 64 * 1024)
+      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, CI, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, CI, true>), grid, block, smem, s, a, ncols, wx, tap_off0);
+  } else {
+    if (smem > 64 * 1024)
+      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, CI, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, CI, false>), grid, block, smem, s, a, ncols, wx, tap_off0);
+  }
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   const ConvW& w = a.w;
-  FMI_REQUIRE(w.w && w.cin_pad % CONV_CI == 0 && w.cout_pad % 32 == 0, "conv: weights not packed");
+  FMI_REQUIRE(w.w && w.cin_pad % 8 == 0 && w.cout_pad % 32 == 0, "conv: weights not packed");
+  {  // profiling switch, re-read per launch (cheap) so that one process can sweep it
+    const char* e = getenv("FMI_CONV_DBG");
+    const_cast<ConvArgs&>(a).dbg = e ? atoi(e) : 0;
+  }
   const int ncols = (a.out_stride == 1) ? a.lout : a.lout / a.out_stride;
   const int tap_off0 = (a.tap_step < 0) ? -(w.taps - 1) * a.tap_step : 0;
   const int span = (w.taps - 1) * (a.tap_step < 0 ? -a.tap_step : a.tap_step) + 1;
   const int ct = w.cout_pad / 32;
-  int MT, NT;
-  if (ct >= 4) { MT = 4; NT = 1; }
-  else if (ct == 3) { MT = 3; NT = 2; }
-  else if (ct == 2) { MT = 2; NT = 2; }
-  else { MT = 1; NT = 4; }
-  const int TT = 4 * NT * 32, CO_T = MT * 32;
-  const int wx = (TT - 1) * a.x_stride + span;
-  const size_t smem = (size_t)(CONV_CI * wx + w.taps * CONV_CI * CO_T) * sizeof(float);
-  FMI_REQUIRE(smem <= 160 * 1024, "conv: LDS tile of %zu bytes exceeds 160 KiB", smem);
-  dim3 grid(cdiv(ncols, TT), cdiv(w.cout_pad, CO_T), a.B * w.phases), block(256);
-#define FMI_CONV(MT_, NT_)                                                                                  \
-  do {                                                                                                      \
-    if (smem > 64 * 1024)                                                                                   \
-      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT_, NT_>,                            \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));            \
-    hipLaunchKernelGGL((conv_mfma_kernel<MT_, NT_>), grid, block, smem, s, a, ncols, wx, tap_off0);         \
-  } while (0)
+  // tile height: the largest of 4/3/2/1 (x32 rows) that divides the channel tiles, so that no
+  // work-group multiplies padding (C = 192 -> 2 x 96, not 128 + 64)
+  int MT = 1;
+  for (int m : {4, 3, 2})
+    if (ct % m == 0) { MT = m; break; }
+  if (ct >= 8 && MT < 4 && ct % 4 != 0 && ct % 3 != 0) MT = 4;  // large odd counts: accept a ragged last tile
+  const bool k1 = (w.taps == 1 && a.x_stride == 1 && w.cin_pad % 32 == 0);
+#define FMI_CONV(MT_, NT_)                                                            \
+  return k1 ? launch_conv_t<MT_, NT_, 32>(a, ncols, tap_off0, span, s)                \
+            : launch_conv_t<MT_, NT_, 8>(a, ncols, tap_off0, span, s)
   if (MT == 4) FMI_CONV(4, 1);
-  else if (MT == 3) FMI_CONV(3, 2);
-  else if (MT == 2) FMI_CONV(2, 2);
-  else FMI_CONV(1, 4);
+  if (MT == 3) FMI_CONV(3, 2);
+  if (MT == 2) FMI_CONV(2, 2);
+  FMI_CONV(1, 4);
 #undef FMI_CONV
-  FMI_CHECK_HIP(hipGetLastError());
-  return FMI_OK;
 }
 
 // =====================================================================================
@@ -546,7 +597,8 @@ __global__ __launch_bounds__(256) void vq_step_kernel(VqArgs a) {
     }
     __syncthreads();
   }
-  const int code = s_besti[0];
+  int code = s_besti[0];
+  if (code < 0 || code >= a.n) code = 0;  // NaN input: no candidate compared greater; never index out of bounds
   if (tid == 0) {
     a.codes[((int64_t)b * a.books + a.book) * a.T + t] = code;
     for (int j = 0; j < d; ++j) {
