@@ -61,6 +61,9 @@ _SIGS = {
     "fmi_dualar_release": (C.c_int, [_P, _I]),
     "fmi_dualar_out_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I)]),
     "fmi_dualar_step": (C.c_int, [_P, _I, _P, _I, _I, C.POINTER(SamplingC), _P, C.c_int32, _P, _P]),
+    "fmi_dualar_forward_slow": (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P]),
+    "fmi_dualar_forward_fast": (C.c_int, [_P, _I, _P, _I, _P, _P]),
+    "fmi_dualar_table_ptr": (C.c_int, [_P, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I)]),
     "fmi_dualar_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_P),
                                         C.POINTER(_P), C.POINTER(_P)]),
     "fmi_dualar_set_trace": (C.c_int, [_P, _I, C.POINTER(_P)]),
@@ -76,6 +79,7 @@ _SIGS = {
     "fmi_dac_finalize_weights": (C.c_int, [_P, _P]),
     "fmi_dac_weights_ready": (C.c_int, [_P]),
     "fmi_dac_decode": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "fmi_dac_decode_latent": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "fmi_dac_encode": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "fmi_dac_frame_length": (C.c_int, [_P]),
     "fmi_dac_debug_z": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I)]),

@@ -412,6 +412,22 @@ int run_convnext(fmi_dac* h, const ConvNeXt& c, float* x, int B, int C, int T) {
   return run_conv(h, c.pw2, hid, x, B, T, nullptr, nullptr, x, c.gamma, ACT_NONE);
 }
 
+// Decoder (modded_dac.py:760-801) on z = X [B][latent][len]; Y = scratch of the peak size
+int run_decoder(fmi_dac* h, float* X, float* Y, int B, int len, float* audio_out_dev) {
+  const fmi_dac_config& c = h->cfg;
+  int l2;
+  FMI_CHECK(run_conv(h, h->dec_in, X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
+  std::swap(X, Y);
+  for (const DecBlock& db : h->dec) {
+    FMI_CHECK(run_conv(h, db.up, X, Y, B, len, &l2, db.alpha, nullptr, nullptr, ACT_NONE));
+    std::swap(X, Y);
+    len = l2;
+    for (int r = 0; r < 3; ++r) FMI_CHECK(run_res_unit(h, db.ru[r], X, Y, B, len));
+  }
+  return launch_final_conv_tanh(X, h->dec_alpha, h->final_w, h->final_b, audio_out_dev, B, c.decoder_dim >> 4, len,
+                                h->stream);
+}
+
 int64_t decode_peak_elems(const fmi_dac_config& c, int T) {
   int64_t peak = (int64_t)c.latent_dim * 4 * T;
   int64_t L = 4 * (int64_t)T;
@@ -600,17 +616,22 @@ int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_
   FMI_CHECK(ensure_buf(h, 5, (int64_t)B * L0 * len));
   FMI_CHECK_HIP(hipMemcpyAsync(h->buf[5].p, X, (size_t)B * L0 * len * 4, hipMemcpyDeviceToDevice, s));
   h->last_z = h->buf[5].p;
-  // Decoder (modded_dac.py:760-801)
-  int l2;
-  FMI_CHECK(run_conv(h, h->dec_in, X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
-  std::swap(X, Y);
-  for (const DecBlock& db : h->dec) {
-    FMI_CHECK(run_conv(h, db.up, X, Y, B, len, &l2, db.alpha, nullptr, nullptr, ACT_NONE));
-    std::swap(X, Y);
-    len = l2;
-    for (int r = 0; r < 3; ++r) FMI_CHECK(run_res_unit(h, db.ru[r], X, Y, B, len));
-  }
-  FMI_CHECK(launch_final_conv_tanh(X, h->dec_alpha, h->final_w, h->final_b, audio_out_dev, B, c.decoder_dim >> 4, len, s));
+  FMI_CHECK(run_decoder(h, X, Y, B, len, audio_out_dev));
+  return sync_out(h, stream);
+}
+
+int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* audio_out_dev, void* stream) {
+  FMI_REQUIRE(h && z_dev && audio_out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "codec weights not ready");
+  FMI_REQUIRE(B >= 1 && L >= 1, "empty input");
+  const fmi_dac_config& c = h->cfg;
+  FMI_CHECK(sync_in(h, stream));
+  // L latent frames = L/4 code frames worth of decoder work
+  const int64_t peak = (int64_t)B * decode_peak_elems(c, cdiv(L, 4));
+  FMI_CHECK(ensure_buf(h, 0, peak));
+  FMI_CHECK(ensure_buf(h, 1, peak));
+  FMI_CHECK_HIP(hipMemcpyAsync(h->buf[0].p, z_dev, (size_t)B * c.latent_dim * L * 4, hipMemcpyDeviceToDevice, h->stream));
+  FMI_CHECK(run_decoder(h, h->buf[0].p, h->buf[1].p, B, L, audio_out_dev));
   return sync_out(h, stream);
 }
 

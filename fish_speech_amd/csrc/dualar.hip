@@ -281,14 +281,21 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
 // everything after the slow transformer for B utterances whose last hidden rows are xl[B][dim]:
 // final norm, restricted tied head, constrained sampling + RAS, the fast-AR chain
 // (decode_one_token_ar, inference.py:108-181).
-int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStream_t s) {
+// final norm + restricted tied head (llama.py:450-457): hn = normed hidden, logits over the live rows
+int tail_head(fmi_dualar* h, const bf16_t* xl, int B, hipStream_t s) {
   const fmi_dualar_config& c = h->cfg;
   const int dim = c.dim;
   // hn = normed hidden (head input, parity tap); hf = its copy that fast step 0 transforms in place
   FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s, h->hf));
   h->launches += 1;
-  FMI_CHECK(linear(h, h->hn, dim, h->head_live, nullptr, nullptr, 0, h->logits, h->n_live_pad, B, h->n_live_pad, dim,
-                   EPI_STORE, s));
+  return linear(h, h->hn, dim, h->head_live, nullptr, nullptr, 0, h->logits, h->n_live_pad, B, h->n_live_pad, dim,
+                EPI_STORE, s);
+}
+
+int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStream_t s) {
+  const fmi_dualar_config& c = h->cfg;
+  const int dim = c.dim;
+  FMI_CHECK(tail_head(h, xl, B, s));
   SampleArgs sa{};
   sa.logits = h->logits; sa.B = B; sa.n = h->n_live; sa.ld = h->n_live_pad; sa.ids = h->live_ids;
   sa.row_slot = row_slot; sa.st = h->st; sa.mode = 0; sa.cb = 0; sa.sem_begin = c.semantic_begin_id;
@@ -321,7 +328,7 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
 }
 
 // one decode frame for the B slots listed in ws.row_slot
-int decode_frame(fmi_dualar* h, int B, hipStream_t s) {
+int decode_frame(fmi_dualar* h, int B, hipStream_t s, bool head_only = false) {
   const fmi_dualar_config& c = h->cfg;
   h->launches = 0;
   EmbedArgs e{};
@@ -332,6 +339,7 @@ int decode_frame(fmi_dualar* h, int B, hipStream_t s) {
   h->launches += 1;
   for (int i = 0; i < c.n_layer; ++i)
     FMI_CHECK(block_slow(h, h->L[i], i, h->ws.x, B, h->ws.row_slot, nullptr, s));
+  if (head_only) return tail_head(h, h->ws.x, B, s);
   return tail(h, h->ws.x, B, h->ws.row_slot, s);
 }
 
@@ -643,7 +651,8 @@ int fmi_dualar_release(fmi_dualar* h, int slot) {
 }
 
 static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int32_t* tokens_dev, const int32_t* lens,
-                        const int32_t* max_new, const fmi_sampling* samp, int frame_index, hipStream_t s) {
+                        const int32_t* max_new, const fmi_sampling* samp, int frame_index, hipStream_t s,
+                        bool head_only = false) {
   const fmi_dualar_config& c = h->cfg;
   int rows = 0;
   for (int i = 0; i < n; ++i) {
@@ -686,6 +695,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
   // the tail addresses slots through row_slot[0..n)
   FMI_CHECK_HIP(hipMemcpyAsync(ws.row_slot, slots.data(), n * 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipStreamSynchronize(s));
+  if (head_only) return tail_head(h, h->xl, n, s);
   return tail(h, h->xl, n, ws.row_slot, s);
 }
 
@@ -814,6 +824,68 @@ int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int po
   }
   FMI_CHECK_HIP(hipMemcpyAsync(out_dev, h->st.cur + (int64_t)slot * ncb1, ncb1 * 4, hipMemcpyDeviceToDevice, s));
   return sync_out(h, stream);
+}
+
+// BaseTransformer.forward_generate (llama.py:390-466): slow transformer + final norm + tied head for one
+// slot; logits over the live rows and the normed hidden state land in the library's tap buffers.
+int fmi_dualar_forward_slow(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int pos0, void* logits_out_dev,
+                            void* hidden_out_dev, void* stream) {
+  FMI_REQUIRE(h && x_dev, "null argument");
+  FMI_REQUIRE(h->ready, "weights not ready");
+  FMI_CHECK(check_slot(h, slot));
+  FMI_REQUIRE(S >= 1, "S must be >= 1");
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  const int ncb1 = h->st.ncb1;
+  fmi_sampling sp{1.0f, 1.0f, 1, 0u, 0};
+  if (S > 1 || pos0 == 0) {
+    FMI_REQUIRE(pos0 == 0, "multi-token call must start at position 0");
+    const int32_t len = S, mn = 0;
+    FMI_CHECK(prefill_impl(h, 1, &slot, x_dev, &len, &mn, &sp, 0, s, true));
+  } else {
+    FMI_REQUIRE(pos0 < h->max_seq, "position %d beyond max_seq_len %d", pos0, h->max_seq);
+    FMI_CHECK(reserve_pages(h, slot, h->max_seq));
+    FMI_CHECK(set_slot(h, slot, pos0, 1, h->max_seq, sp, false));
+    FMI_CHECK_HIP(hipMemcpyAsync(h->st.cur + (int64_t)slot * ncb1, x_dev, ncb1 * 4, hipMemcpyDeviceToDevice, s));
+    FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
+    FMI_CHECK_HIP(hipStreamSynchronize(s));
+    FMI_CHECK(decode_frame(h, 1, s, true));
+  }
+  if (logits_out_dev)
+    FMI_CHECK_HIP(hipMemcpyAsync(logits_out_dev, h->logits, (size_t)h->n_live * 2, hipMemcpyDeviceToDevice, s));
+  if (hidden_out_dev)
+    FMI_CHECK_HIP(hipMemcpyAsync(hidden_out_dev, h->hn, (size_t)h->cfg.dim * 2, hipMemcpyDeviceToDevice, s));
+  return sync_out(h, stream);
+}
+
+// DualARTransformer.forward_generate_fast (llama.py:799-817): one fast-AR position for one slot.
+int fmi_dualar_forward_fast(fmi_dualar* h, int slot, const void* hidden_in_dev, int pos, void* logits_out_dev,
+                            void* stream) {
+  FMI_REQUIRE(h && hidden_in_dev && logits_out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "weights not ready");
+  FMI_CHECK(check_slot(h, slot));
+  const fmi_dualar_config& c = h->cfg;
+  FMI_REQUIRE(pos >= 0 && pos < c.num_codebooks, "fast position %d out of range", pos);
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  FMI_CHECK_HIP(hipMemcpyAsync(h->xf, hidden_in_dev, (size_t)c.fast_dim * 2, hipMemcpyDeviceToDevice, s));
+  FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, 1, pos, h->ws.row_slot, s));
+  FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, 1,
+                   c.codebook_size, c.fast_dim, EPI_STORE, s));
+  FMI_CHECK_HIP(hipMemcpyAsync(logits_out_dev, h->flogits, (size_t)c.codebook_size * 2, hipMemcpyDeviceToDevice, s));
+  return sync_out(h, stream);
+}
+
+// Row-major tables inside the arena that the host mirror may index itself (embedding lookups are
+// tensor plumbing): which = 0 fast_embeddings (codebook_size x fast_dim bf16), 1 live ids (int32 n_live)
+int fmi_dualar_table_ptr(fmi_dualar* h, int which, void** ptr, int* rows, int* cols) {
+  FMI_REQUIRE(h && ptr, "null argument");
+  if (which == 0) { *ptr = h->fast_emb; if (rows) *rows = h->cfg.codebook_size; if (cols) *cols = h->cfg.fast_dim; }
+  else if (which == 1) { *ptr = h->live_ids; if (rows) *rows = h->n_live; if (cols) *cols = 1; }
+  else return set_error(FMI_EINVAL, "unknown table %d", which);
+  return FMI_OK;
 }
 
 int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* ld_logits, void** live_ids,

@@ -289,6 +289,18 @@ class MiDAC:
         self._keep = work
         return out
 
+    # ---- DAC.decode (modded_dac.py:929-946): latent z (B, latent_dim, L) -> waveform
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        B, Cc, L = z.shape
+        if Cc != self.config.latent_dim:
+            raise ValueError(f"expected {self.config.latent_dim} latent channels, got {Cc}")
+        out = torch.empty(B, 1, L * self.hop_length, dtype=torch.float32, device=self.device)
+        check(self.lib.fmi_dac_decode_latent(self._h, C.c_void_p(z.data_ptr()), B, L, C.c_void_p(out.data_ptr()), self._stream()))
+        self._keep = z
+        return out
+
     def debug_z(self, B: int) -> torch.Tensor:
         """quantizer.decode output (B, latent_dim, 4T) of the last from_indices call (parity tap)."""
         from .dual_ar import _from_ptr

@@ -323,6 +323,44 @@ class MiDualAR:
         self.max_batch_size, self.max_seq_len = max_batch_size, max_seq_len
         self._cache_setup_done = True
 
+    # ---- the model-object seam (llama.py:390-466, 799-828) for callers keeping decode_one_token_ar
+    def _table(self, which: int, dtype) -> torch.Tensor:
+        p, r, c = C.c_void_p(), C.c_int(), C.c_int()
+        check(self.lib.fmi_dualar_table_ptr(self._h, which, C.byref(p), C.byref(r), C.byref(c)))
+        return _from_ptr(p.value, (r.value, c.value), dtype, self.device)
+
+    def forward_generate(self, x: torch.Tensor, input_pos: Optional[torch.Tensor] = None, audio_masks=None,
+                         audio_parts=None) -> "ForwardResult":
+        """x: (1, 1+ncb, S) integer.  Returns logits (1, 1, vocab) -- finite only on the constrained rows,
+        which is what survives the reference's semantic_logit_bias anyway -- and hidden_states (1, 1, dim)."""
+        cfg = self.config
+        if not self._cache_setup_done:
+            self.setup_caches(1, cfg.max_seq_len)
+        ncb1 = cfg.num_codebooks + 1
+        xs = x.reshape(ncb1, -1).t().to(device=self.device, dtype=torch.int32).contiguous()
+        pos0 = 0 if input_pos is None else int(input_pos.reshape(-1)[0].item())
+        ids = self._table(1, torch.int32).view(-1).long()
+        live = torch.empty(ids.numel(), dtype=torch.bfloat16, device=self.device)
+        hidden = torch.empty(cfg.dim, dtype=torch.bfloat16, device=self.device)
+        check(self.lib.fmi_dualar_forward_slow(self._h, 0, C.c_void_p(xs.data_ptr()), int(xs.shape[0]), pos0,
+                                               C.c_void_p(live.data_ptr()), C.c_void_p(hidden.data_ptr()), self._stream()))
+        logits = torch.full((1, 1, cfg.vocab_size), float("-inf"), dtype=torch.bfloat16, device=self.device)
+        logits[0, 0, ids] = live
+        self._keep = xs
+        return ForwardResult(logits=logits, hidden_states=hidden.view(1, 1, -1))
+
+    def forward_generate_fast(self, x: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
+        cfg = self.config
+        hid = x.reshape(-1).to(device=self.device, dtype=torch.bfloat16).contiguous()
+        out = torch.empty(cfg.codebook_size, dtype=torch.bfloat16, device=self.device)
+        check(self.lib.fmi_dualar_forward_fast(self._h, 0, C.c_void_p(hid.data_ptr()), int(input_pos.reshape(-1)[0].item()),
+                                               C.c_void_p(out.data_ptr()), self._stream()))
+        self._keep = hid
+        return out.view(1, 1, -1)
+
+    def fast_embeddings(self, idx: torch.Tensor) -> torch.Tensor:
+        return self._table(0, torch.bfloat16)[idx.to(self.device).long()]
+
     # ---- batched API (new capability)
     def _sampling(self, temperature, top_p, top_k, seed, use_ras=True) -> SamplingC:
         return SamplingC(float(temperature), float(top_p), int(top_k), int(seed) & 0xFFFFFFFF, int(bool(use_ras)))

@@ -119,6 +119,20 @@ int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int po
                     const fmi_sampling* samp, const int32_t* prev_dev, int32_t frame_index,
                     int32_t* out_dev, void* stream);
 
+/* The model-object seam of SURVEY.md 8b, for callers that keep the reference's own
+ * decode_one_token_ar: BaseTransformer.forward_generate (llama.py:390-466, slow transformer + final norm
+ * + tied head; logits bf16 over the n_live constrained rows -- every other vocabulary row is -inf after
+ * semantic_logit_bias, inference.py:310-320 -- hidden bf16 [dim]) and
+ * DualARTransformer.forward_generate_fast (llama.py:799-817; hidden bf16 [fast_dim] at codebook
+ * position pos -> logits bf16 [codebook_size]).  Batch 1 like the reference. */
+int fmi_dualar_forward_slow(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int pos0,
+                            void* logits_out_dev, void* hidden_out_dev, void* stream);
+int fmi_dualar_forward_fast(fmi_dualar* h, int slot, const void* hidden_in_dev, int pos,
+                            void* logits_out_dev, void* stream);
+/* Row-major tables inside the arena for host-side lookups: which = 0 fast_embeddings
+ * (codebook_size x fast_dim bf16), 1 = vocab id of each live logits row (int32 [n_live]). */
+int fmi_dualar_table_ptr(fmi_dualar* h, int which, void** ptr, int* rows, int* cols);
+
 /* Debug / parity taps (device pointers owned by the library, valid until the next call):
  * live-row logits of the last slow step (bf16, [B][n_live_padded]), the vocab id of each
  * live row (int32 [n_live]), the normed hidden (bf16 [B][dim]) and the fast logits of the
@@ -195,6 +209,8 @@ int fmi_dac_weights_ready(fmi_dac* h);
  * (rvq.py:354-359) the indices are clamped IN PLACE. */
 int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_out_dev,
                    void* stream);
+/* DAC.decode (modded_dac.py:929-946): latent z fp32 (B, latent_dim, L) -> audio fp32 (B,1,L*hop_length). */
+int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* audio_out_dev, void* stream);
 /* DAC.encode (modded_dac.py:874-923): audio fp32 (B,1,N) (N already padded to a multiple of
  * frame_length by the caller shim) -> indices int64 (B,1+n_codebooks,N/frame_length). */
 int fmi_dac_encode(fmi_dac* h, const float* audio_dev, int B, int N, int64_t* indices_out_dev,

@@ -114,3 +114,27 @@ def test_causal_prefix_and_batch_invariance_at_10s(full):
     assert torch.equal(one[0], both[1])
     part = codec.from_indices(codes[:1, :, :100].clone())
     assert float((part[0, 0] - both[0, 0, : 100 * 2048]).abs().max()) <= 2e-5
+
+
+def test_config0_3s_clip_encode_decode_vs_oracle(full):
+    """BASELINE configs[0]: encode -> decode of one 3 s 44.1 kHz mono clip (132 300 samples, padded to
+    133 120 = 65 frames), yaml-sized codec, against the CPU oracle: codes bit-exact, waveform RMS <= 1e-4;
+    plus DAC.decode(z) on the quantizer's latent equals from_indices."""
+    cfg, state, codec = full
+    n = 3 * cfg.sample_rate
+    g = torch.Generator().manual_seed(21)
+    t = torch.arange(n) / cfg.sample_rate
+    audio = (0.3 * torch.sin(2 * np.pi * 220 * t) + 0.02 * torch.randn(n, generator=g)).view(1, 1, n)
+    codes, lens = codec.encode(audio.to(DEV), torch.tensor([n], device=DEV))
+    assert codes.shape == (1, 10, 65) and lens.tolist() == [65]
+    orc = D.DacOracle(cfg, state)
+    want_codes, _ = orc.encode(audio, torch.tensor([n]))
+    agree = float((codes.cpu() == want_codes).float().mean())
+    print("3 s clip: code agreement with the oracle", agree)
+    assert torch.equal(codes.cpu(), want_codes)
+    wav = codec.from_indices(codes.clone())
+    want = orc.from_indices(want_codes.clone())
+    assert wav.shape == (1, 1, 65 * 2048)
+    assert rms(wav, want) <= 1e-4
+    z = codec.debug_z(1)
+    assert torch.equal(codec.decode(z), wav)

@@ -266,3 +266,129 @@ def test_im_end_stops_generation_and_bounds():
     out = generate(model=model, prompt=O.make_prompt(cfg, 10, 2), max_new_tokens=cfg.max_seq_len, top_k=1,
                    temperature=0.7, top_p=0.7, poll_every=4)
     assert out.shape[1] <= cfg.max_seq_len  # clamp of inference.py:268-275
+
+
+# ------------------------------------------------------------------------------- BASELINE-size properties
+
+
+@pytest.fixture(scope="module")
+def s2_model():
+    """S2-Pro-shaped 4.56 B parameter model with random weights generated on the GPU (bench.py's)."""
+    import bench
+    from fish_speech_amd.dual_ar import MiDualAR
+
+    cfg = bench.s2_pro_config(max_seq_len=512)
+    model = MiDualAR(cfg, device=DEV, im_end_id=cfg.im_end_id)
+    model.load_state_dict(bench.synthetic_state_on_device(cfg, torch.device(DEV)))
+    model.setup_caches(8, 512)
+    model.set_ignore_eos(True)
+    return cfg, model
+
+
+def test_s2_shape_ragged_batch_equals_single_and_graph_equals_eager(s2_model):
+    """Size-independent properties at the BASELINE model size (36+4 layers, dim 2560, vocab 155 776):
+    a ragged batch of 8 (config 4: mixed-length prompts) gives, for every utterance, exactly the
+    tokens of its batch-1 run; hipGraph replay equals eager launches; all codes are in range."""
+    from fish_speech_amd.dual_ar import generate_batch
+
+    cfg, model = s2_model
+    lens = [200, 57, 400, 131, 64, 333, 200, 90]
+    prompts = []
+    for i, T in enumerate(lens):
+        g = torch.Generator().manual_seed(100 + i)
+        p = torch.zeros(cfg.num_codebooks + 1, T, dtype=torch.int64)
+        p[0] = torch.randint(0, 150000, (T,), generator=g)
+        if i % 2:  # voice-clone shaped: semantic tail with codes
+            ns = T // 3
+            codes = torch.randint(0, cfg.codebook_size, (cfg.num_codebooks, ns), generator=g)
+            p[1:, T - ns:] = codes
+            p[0, T - ns:] = codes[0] + cfg.semantic_begin_id
+        prompts.append(p)
+    seeds = list(range(50, 58))
+    kw = dict(max_new_tokens=10, temperature=0.7, top_p=0.7, top_k=30, stop_on_im_end=False)
+    model.set_graph(True)
+    batch = generate_batch(model=model, prompts=prompts, seeds=seeds, **kw)
+    model.set_graph(False)
+    eager = generate_batch(model=model, prompts=prompts, seeds=seeds, **kw)
+    model.set_graph(True)
+    for i in range(8):
+        assert batch[i].shape == (cfg.num_codebooks + 1, lens[i] + 10)
+        assert torch.equal(batch[i], eager[i]), f"graph != eager for utterance {i}"
+        gen = batch[i][:, lens[i]:]
+        assert int(gen[1:].min()) >= 0 and int(gen[1:].max()) < cfg.codebook_size
+        tok = gen[0]
+        ok = ((tok >= cfg.semantic_begin_id) & (tok <= cfg.semantic_end_id)) | (tok == cfg.im_end_id) | (tok == 0)
+        assert bool(ok.all()), "slow token outside the constrained set (semantic ids, <|im_end|>, or the u==0 token 0)"
+    for i in (2, 5):  # batch-1 runs in the same slot (slot = uniform stream id)
+        single = generate_batch(model=model, prompts=[prompts[0]] * i + [prompts[i]], seeds=seeds[: i + 1], **kw)[-1]
+        assert torch.equal(single, batch[i]), f"batch result of utterance {i} differs from its batch-1 run"
+
+
+def test_s2_shape_device_codes_feed_codec_shape(s2_model):
+    from fish_speech_amd.dual_ar import generate_batch_device
+
+    cfg, model = s2_model
+    prompts = [torch.zeros(cfg.num_codebooks + 1, 20, dtype=torch.int64) for _ in range(3)]
+    for i, p in enumerate(prompts):
+        p[0] = torch.randint(0, 150000, (20,), generator=torch.Generator().manual_seed(i))
+    codes = generate_batch_device(model=model, prompts=prompts, max_new_tokens=7, seeds=[1, 2, 3], temperature=0.7,
+                                  top_p=0.7, top_k=30)
+    assert codes.shape == (3, cfg.num_codebooks, 7) and codes.dtype == torch.int64 and codes.is_cuda
+    assert int(codes.min()) >= 0 and int(codes.max()) < cfg.codebook_size
+
+
+# ------------------------------------------------------------------------------- model-object seam
+
+
+class _SeamAdapter:
+    """Lets the oracle's restatement of decode_one_token_ar (inference.py:96-181) drive the HIP model
+    through the model-object seam: forward_generate / forward_generate_fast / fast_embeddings."""
+
+    def __init__(self, model, cfg):
+        self.m, self.cfg, self.trace = model, cfg, None
+
+    def forward_generate(self, x, input_pos, math_backend):
+        r = self.m.forward_generate(x.to(DEV), input_pos.to(DEV))
+        return r.logits.cpu(), r.hidden_states.cpu()
+
+    def forward_generate_fast(self, h, pos):
+        return self.m.forward_generate_fast(h.to(DEV), pos).cpu()
+
+    def fast_embeddings(self, a):
+        return self.m.fast_embeddings(a.to(DEV)).cpu()
+
+
+@pytest.mark.parametrize("case,top_k", [("tiny", 30), ("mid", 30), ("mid", 1)])
+def test_reference_decode_function_over_hip_model_equals_hip_step(case, top_k):
+    """The reference's decode_one_token_ar logic (oracle restatement: torch sort/softmax/cumsum sampler,
+    RAS, fast chain) running on the HIP model's forward_generate/forward_generate_fast must produce,
+    frame after frame, exactly the tokens of the fused HIP step (fmi_dualar_step): same logits, and a
+    HIP sampler that is bit-exact to the reference's sampling semantics."""
+    from fish_speech_amd.dual_ar import decode_one_token
+
+    cfg, state, z = load_dualar_case(case)
+    model = _make_model(cfg, state)
+    ad = _SeamAdapter(model, cfg)
+    prompt = torch.from_numpy(z["prompt"])
+    T = prompt.shape[1]
+    ncb1 = cfg.num_codebooks + 1
+    bias = O.semantic_logit_bias(cfg, torch.bfloat16)
+    temp = torch.tensor(0.7).bfloat16()
+    u = O.FmiUniform(4321, 0)
+    window = torch.zeros(ncb1, 10, dtype=torch.int32)
+    cur, pos = prompt.view(1, ncb1, -1), torch.arange(T)
+    n_same = 0
+    for f in range(12):
+        u.frame, u.draw_idx = f, 0
+        prev = None if f == 0 else window.clone()
+        want = O.decode_one_token(ad, cur, pos, temp, temp, top_k, bias, prev, u, math_backend=True).view(-1)
+        sp = model._sampling(0.7, 0.7, top_k, 4321, prev is not None)
+        xs = cur.reshape(ncb1, -1).t().int().contiguous().to(DEV)
+        got = model.step(xs, int(pos[0]), sp, prev.to(DEV) if prev is not None else None, f).cpu()
+        assert torch.equal(got.long(), want.long()), f"frame {f}: fused step {got.tolist()} != seam path {want.tolist()}"
+        n_same += 1
+        if f > 0:
+            window = window.roll(-1, dims=1)
+            window[:, -1] = want.int()
+        cur, pos = want.view(1, ncb1, 1).long(), torch.tensor([T + f])
+    assert n_same == 12
