@@ -157,16 +157,29 @@ __device__ inline float row_rstd(const bf16_t* __restrict__ x, int K, float eps,
   return rsqrtf(ss / (float)K + eps);
 }
 
+// two fp32 -> packed bf16 pair, round-to-nearest-even (one VALU instruction on gfx950; no builtin)
+__device__ inline uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// RMSNorm of one 8-element fragment: bf16(bf16(x * rstd) * w), both roundings RNE like the reference's
+// `.type_as(x) * weight` (llama.py:999-1001).  Works on packed pairs: ~6 VALU ops per element.
 __device__ inline bf16x8 norm_frag(uint4 xv, uint4 wv, float rstd) {
-  const bf16_t* xe = reinterpret_cast<const bf16_t*>(&xv);
-  const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
-  bf16x8 o;
+  const uint32_t* xp = reinterpret_cast<const uint32_t*>(&xv);
+  const uint32_t* wp = reinterpret_cast<const uint32_t*>(&wv);
+  uint4 o;
+  uint32_t* op = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float n = rbf(bf2f(xe[j]) * rstd);
-    o[j] = (short)f2bf(n * bf2f(we[j]));
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = __uint_as_float(xp[j] << 16), x1 = __uint_as_float(xp[j] & 0xffff0000u);
+    const uint32_t n = cvt_pk_bf16(x0 * rstd, x1 * rstd);
+    const float n0 = __uint_as_float(n << 16), n1 = __uint_as_float(n & 0xffff0000u);
+    const float w0 = __uint_as_float(wp[j] << 16), w1 = __uint_as_float(wp[j] & 0xffff0000u);
+    op[j] = cvt_pk_bf16(n0 * w0, n1 * w1);
   }
-  return o;
+  return *reinterpret_cast<bf16x8*>(&o);
 }
 
 __global__ void rmsnorm_rows_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w, float eps,
@@ -341,6 +354,97 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
   }
 }
 
+// "Burst" variant for the case where a wave's whole K slice fits in registers (KTW k-tiles per wave,
+// K = 32 * WAVES * KTW): every weight tile of the wave is requested before anything else happens, so the
+// HBM stream runs at full depth while the RMSNorm row statistics (an L2 round trip + reduction) are
+// computed, instead of stalling behind them.
+template <int WAVES, int EPI, bool NORM, int KTW, int TILES>
+__global__ __launch_bounds__(WAVES * 64) void linear_skinny_burst_kernel(LinearArgs a) {
+  static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
+  __shared__ float red[WAVES][TILES][256];
+  __shared__ float s_rstd[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = lane & 15, g = lane >> 4;
+  constexpr int KT = WAVES * KTW;
+  const int tile0 = blockIdx.x * TILES;
+  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
+  const int kbeg = wave * KTW;
+
+  u32x4 wv[TILES][KTW];
+#pragma unroll
+  for (int u = 0; u < KTW; ++u)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+      wv[t][u] = __builtin_nontemporal_load(wp + ((int64_t)(tile0 + t) * KT + kbeg + u) * 64 + lane);
+
+  float rstd = 0.f;
+  if (NORM) {
+    for (int r = wave; r < a.M; r += WAVES) {
+      float v = row_rstd(a.x + (int64_t)r * a.ldx, a.K, a.eps, lane);
+      if (lane == 0) s_rstd[r] = v;
+    }
+    __syncthreads();
+    if (b < a.M) rstd = s_rstd[b];
+  }
+  const bool bvalid = b < a.M;
+  const bf16_t* xrow = a.x + (int64_t)(bvalid ? b : 0) * a.ldx + g * 8;
+  const bf16_t* nrow = NORM ? a.norm_w + g * 8 : nullptr;
+
+  f32x4 acc[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < KTW; ++u) {
+    uint4 xv = bvalid ? *reinterpret_cast<const uint4*>(xrow + (kbeg + u) * 32) : make_uint4(0, 0, 0, 0);
+    bf16x8 xb;
+    if (NORM) {
+      uint4 nv = *reinterpret_cast<const uint4*>(nrow + (kbeg + u) * 32);
+      xb = norm_frag(xv, nv, rstd);
+    } else {
+      xb = *reinterpret_cast<bf16x8*>(&xv);
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[t][u]), xb, acc[t], 0, 0, 0);
+  }
+
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[t];
+  __syncthreads();
+  if (tid < 256) {
+    const int bb = tid >> 4, r = tid & 15;
+    if (bb < a.M) {
+      const int ridx = (((r >> 2) * 16) + bb) * 4 + (r & 3);
+      float v[TILES];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sacc += red[w][t][ridx];
+        v[t] = sacc;
+      }
+      if (EPI == EPI_STORE) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) a.out[(int64_t)bb * a.ldo + (tile0 + t) * 16 + r] = f2bf(v[t]);
+      } else if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          const int n = (tile0 + t) * 16 + r;
+          a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + rbf(v[t]));
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < TILES; t += 2) {
+          const int n = ((tile0 + t) >> 1) * 16 + r;
+          float gate = rbf(silu_f(rbf(v[t])));
+          float up = rbf(v[t + 1 < TILES ? t + 1 : t]);
+          a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
+        }
+      }
+    }
+  }
+}
+
 template <int WAVES, int UNR, int TILES>
 static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
   const bool norm = a.norm_w != nullptr;
@@ -356,12 +460,14 @@ static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
 }
 
 // Variant choice from tools/gemv_bench.hip on MI355X (profiles/gemv_bench_r01.txt), M = 8:
-//   w13  (19456x2560, norm, SwiGLU)  8 waves, UNR 2, 2 tiles : 26.3 us (3.79 TB/s)
-//   wqkv (6144x2560, norm)          16 waves, UNR 2, 2 tiles : 13.3 us (2.37 TB/s)
-//   wo   (2560x4096, residual)      16 waves, UNR 2, 1 tile  :  6.9 us (3.04 TB/s)
-//   w2   (2560x9728, residual)       8 waves, UNR 4, 1 tile  : 13.3 us (3.75 TB/s)
-// A bare streaming read of the same bytes per launch reaches 3.6 / 4.1 / 4.4 / 5.0 TB/s at
+//   w13  (19456x2560, norm, SwiGLU)  8 waves, UNR 2, 2 tiles : 21.8 us (4.56 TB/s)
+//   wqkv (6144x2560, norm)           8 waves, UNR 2, 2 tiles : 10.0 us (3.16 TB/s)
+//   wo   (2560x4096, residual)       8 waves, UNR 4, 1 tile  :  6.7 us (3.11 TB/s)
+//   w2   (2560x9728, residual)       8 waves, UNR 4, 1 tile  : 13.4 us (3.73 TB/s)
+// A bare streaming read of the same bytes per launch reaches 3.6 / 4.1 / 4.4 / 5.1 TB/s at
 // 21 / 32 / 50 / 100 MiB (about 3 us of every launch is ramp), 6.4-6.6 TB/s at 1 GiB.
+// (The norm-fused variants were VALU-bound on software bf16 rounding until norm_frag moved to
+// v_cvt_pk_bf16_f32: 26.4 -> 21.8 us and 13.5 -> 10.0 us.)
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   FMI_REQUIRE(a.M >= 1 && a.M <= 16, "linear_skinny: M=%d not in [1,16]", a.M);
   FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0, "linear_skinny: bad shape N=%d K=%d", a.N, a.K);
@@ -373,12 +479,11 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
     return launch_skinny_t<4, 1, 1>(a, s);
   }
   if (a.epi == EPI_SILU) return launch_skinny_t<8, 2, 2>(a, s);
-  if (a.norm_w) {  // norm-fused projections (wqkv, LM head, fast_output)
-    if (ntile % 2 == 0) return launch_skinny_t<16, 2, 2>(a, s);
-    return launch_skinny_t<16, 2, 1>(a, s);
+  if (a.norm_w) {  // norm-fused projections (wqkv, fast_output)
+    if (ntile % 2 == 0) return launch_skinny_t<8, 2, 2>(a, s);
+    return launch_skinny_t<8, 2, 1>(a, s);
   }
-  if (KT >= 256) return launch_skinny_t<8, 4, 1>(a, s);   // w2: long K
-  return launch_skinny_t<16, 2, 1>(a, s);                 // wo
+  return launch_skinny_t<8, 4, 1>(a, s);  // wo, w2, LM head
 }
 
 // =====================================================================================
