@@ -64,6 +64,51 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// ---- DPP reductions: 16-lane rows reduce inside the VALU (no ds_bpermute round trips) ----
+template <int CTRL>
+__device__ inline float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ inline int dpp_i(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+// all-reduce (sum) over aligned groups of N lanes, N in {4, 8, 16}; every lane gets the group total
+template <int N>
+__device__ inline float group_allsum(float v) {
+  v += dpp_f<0xB1>(v);                 // quad_perm(1,0,3,2)
+  v += dpp_f<0x4E>(v);                 // quad_perm(2,3,0,1)
+  if (N >= 8) v += dpp_f<0x141>(v);    // row_half_mirror
+  if (N >= 16) v += dpp_f<0x140>(v);   // row_mirror
+  return v;
+}
+// full-wave reductions: rows by DPP, the four row totals by scalar broadcasts (result is wave-uniform)
+__device__ inline float wave_sum_dpp(float v) {
+  v = group_allsum<16>(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return ((r0 + r1) + r2) + r3;
+}
+__device__ inline int wave_sum_dpp_i(int v) {
+  v += dpp_i<0xB1>(v);
+  v += dpp_i<0x4E>(v);
+  v += dpp_i<0x141>(v);
+  v += dpp_i<0x140>(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+__device__ inline uint32_t wave_max_dpp_u(uint32_t v) {
+  v = max(v, (uint32_t)dpp_i<0xB1>((int)v));
+  v = max(v, (uint32_t)dpp_i<0x4E>((int)v));
+  v = max(v, (uint32_t)dpp_i<0x141>((int)v));
+  v = max(v, (uint32_t)dpp_i<0x140>((int)v));
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

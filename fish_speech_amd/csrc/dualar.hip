@@ -260,7 +260,7 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
 }
 
 int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int pos, const int32_t* row_slot,
-               hipStream_t s) {
+               hipStream_t s, bool kv_only = false) {
   const Dims& d = h->fast;
   Workspace& ws = h->ws;
   FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s));
@@ -272,6 +272,7 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
   a.ncb = h->cfg.num_codebooks; a.pos = pos; a.eps = h->cfg.norm_eps;
   FMI_CHECK(launch_fast_attn(a, s));
   h->launches += 1;
+  if (kv_only) return FMI_OK;  // only this layer's K/V at `pos` were needed
   FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s));
   FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s));
   FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s));
@@ -307,7 +308,10 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   bf16_t* f0 = h->hf;
   if (!c.norm_fastlayer_input)
     FMI_CHECK_HIP(hipMemcpyAsync(h->hf, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
-  for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, f0, B, 0, row_slot, s));
+  // Fast step 0 exists only to put the hidden state's K/V into slot 0 of every fast layer: its logits are
+  // discarded (inference.py:148-149), so the last layer's wo / FFN output feeds nothing and is skipped.
+  for (int i = 0; i < c.n_fast_layer; ++i)
+    FMI_CHECK(block_fast(h, h->FL[i], i, f0, B, 0, row_slot, s, i == c.n_fast_layer - 1));
   for (int cb = 1; cb < c.num_codebooks; ++cb) {
     for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, B, cb, row_slot, s));
     FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, B,

@@ -694,8 +694,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       float d = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) d += q[gq][j] * kf[j];
-#pragma unroll
-      for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      d = group_allsum<LPT>(d);
       if (valid) {
         const float sc = d * scale;
         const float mn = fmaxf(m[gq], sc);
@@ -860,8 +859,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
       float d = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) d += q[gq][j] * kf[j];
-#pragma unroll
-      for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      d = group_allsum<LPT>(d);
       if (valid) {
         const float sc = d * scale;
         const float mn = fmaxf(m[gq], sc);
@@ -973,10 +971,14 @@ int launch_attn_decode_fused(const AttnArgs& a, hipStream_t s) {
   }
 }
 
-// fast-AR attention (llama.py:948-976), S <= num_codebooks, everything rounded through bf16 like
-// the reference's explicit matmul/softmax chain.  grid (B, KVH), 4 waves.
+// fast-AR attention (llama.py:948-976), S <= num_codebooks <= 16, everything rounded through bf16 like
+// the reference's explicit matmul/softmax chain.  grid (B, KVH), 4 waves; a wave serves query heads
+// g = wave, wave+4, ...  All keys are scored in parallel: lane = (key t, 32-dim chunk c), partial dots
+// meet by a 4-lane DPP sum; the weighted sum of values runs with lanes along the head dimension.
 __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
   __shared__ float s_k[128], s_v[128];
+  __shared__ float s_q[4][128];
+  __shared__ float s_p[4][16];
   const int b = blockIdx.x, kvh = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int D = a.D, H = a.H, KVH = a.KVH, G = H / KVH;
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
     float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
     float y0 = x0, y1 = x1;
     if (a.knw) {
-      float ss = wave_sum(x0 * x0 + x1 * x1);
+      float ss = wave_sum_dpp(x0 * x0 + x1 * x1);
       float rstd = rsqrtf(ss / (float)D + a.eps);
       y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.knw[2 * p])));
       y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.knw[2 * p + 1])));
@@ -1018,61 +1020,69 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
   __syncthreads();
 
   const float scale = (float)(1.0 / sqrt((double)D));
+  const int CH = D / 4;               // dims per chunk lane (32 for D = 128)
+  const int kt = lane >> 2, kcn = lane & 3;  // lane = (key, chunk)
   for (int gq = wave; gq < G; gq += 4) {
     const int h = kvh * G + gq;
     uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
     float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
     float y0 = x0, y1 = x1;
     if (a.qnw) {
-      float ss = wave_sum(x0 * x0 + x1 * x1);
+      float ss = wave_sum_dpp(x0 * x0 + x1 * x1);
       float rstd = rsqrtf(ss / (float)D + a.eps);
       y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.qnw[2 * p])));
       y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.qnw[2 * p + 1])));
     }
-    const float q0 = rbf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
-    const float q1 = rbf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
-    // all cached rows are fetched up front (unconditional, clamped) so the loads overlap
-    uint32_t kr[16], vr[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int tc = t < a.ncb ? t : a.ncb - 1;
-      kr[t] = *reinterpret_cast<const uint32_t*>(kc + (int64_t)tc * D + 2 * p);
-      vr[t] = *reinterpret_cast<const uint32_t*>(vc + (int64_t)tc * D + 2 * p);
+    if (act) {
+      s_q[wave][2 * p] = rbf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
+      s_q[wave][2 * p + 1] = rbf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
     }
-    float sc[16];
-    float mx = -INFINITY;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // scores: lane (kt, kcn) takes dims [kcn*CH, +CH) of key kt; keys > pos are masked out
+    float d = 0.f;
+    if (kt <= pos) {
+      if (kt == pos) {
+        for (int j = 0; j < CH; ++j) d += s_q[wave][kcn * CH + j] * s_k[kcn * CH + j];
+      } else {
+        const bf16_t* kr = kc + (int64_t)kt * D + kcn * CH;
+        for (int j = 0; j < CH; j += 8) {
+          uint4 kv8 = *reinterpret_cast<const uint4*>(kr + j);
+          const bf16_t* ke = reinterpret_cast<const bf16_t*>(&kv8);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      sc[t] = 0.f;
-      if (t <= pos) {
-        float k0 = bf2f((bf16_t)(kr[t] & 0xffff)), k1 = bf2f((bf16_t)(kr[t] >> 16));
-        if (t == pos) {
-          k0 = s_k[2 * p];
-          k1 = s_k[2 * p + 1];
+          for (int e = 0; e < 8; ++e) d += s_q[wave][kcn * CH + j + e] * bf2f(ke[e]);
         }
-        float d = act ? (q0 * k0 + q1 * k1) : 0.f;
-        d = wave_sum(d);
-        // query @ key^T -> bf16, * scale -> bf16 (llama.py:971)
-        sc[t] = rbf(rbf(d) * scale);
-        mx = fmaxf(mx, sc[t]);
       }
     }
-    float sum = 0.f;
+    d = group_allsum<4>(d);
+    // query @ key^T -> bf16, * scale -> bf16 (llama.py:971); masked keys -> -inf
+    const float sc = (kt <= pos) ? rbf(rbf(d) * scale) : -INFINITY;
+    if (kcn == 0) s_p[wave][kt] = sc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float mx = -INFINITY, e[16], sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (t <= pos) {
-        sc[t] = expf(sc[t] - mx);
-        sum += sc[t];
-      }
+    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, s_p[wave][t]);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      e[t] = (t <= pos) ? expf(s_p[wave][t] - mx) : 0.f;
+      sum += e[t];
+    }
     float o0 = 0.f, o1 = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t)
       if (t <= pos) {
-        const float pr = rbf(sc[t] / sum);  // softmax output rounded to bf16
-        float v0 = bf2f((bf16_t)(vr[t] & 0xffff)), v1 = bf2f((bf16_t)(vr[t] >> 16));
+        const float pr = rbf(e[t] / sum);  // softmax output rounded to bf16
+        float v0, v1;
         if (t == pos) {
           v0 = s_v[2 * p];
           v1 = s_v[2 * p + 1];
+        } else {
+          const uint32_t vr = *reinterpret_cast<const uint32_t*>(vc + (int64_t)t * D + 2 * p);
+          v0 = bf2f((bf16_t)(vr & 0xffff));
+          v1 = bf2f((bf16_t)(vr >> 16));
         }
         o0 += pr * v0;
         o1 += pr * v1;
@@ -1084,7 +1094,7 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
 }
 
 int launch_fast_attn(const FastAttnArgs& a, hipStream_t s) {
-  FMI_REQUIRE(a.D <= 128 && a.D % 2 == 0 && a.ncb <= 16 && a.pos < a.ncb, "fast_attn: unsupported shape");
+  FMI_REQUIRE(a.D <= 128 && a.D % 32 == 0 && a.ncb <= 16 && a.pos < a.ncb, "fast_attn: unsupported shape");
   hipLaunchKernelGGL(fast_attn_kernel, dim3(a.B, a.KVH), dim3(256), 0, s, a);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
@@ -1474,7 +1484,7 @@ __device__ inline int small_draw(float v, float cum, int vid, int lane, int k, f
   const float lt = rbf(v / tc);
   const float l0 = __shfl(lt, 0, 64);
   const float e = keep ? expf(lt - l0) : 0.f;
-  const float esum = wave_sum(e);
+  const float esum = wave_sum_dpp(e);
   float best = -1.f;
   int best_id = 0x7fffffff;
   if (e > 0.f) {
@@ -1540,8 +1550,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
       kmax = max(kmax, key);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+  kmax = wave_max_dpp_u(kmax);
   if (lane == 0) sh.wmax[wave] = kmax;
   __syncthreads();
   kmax = max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
@@ -1554,7 +1563,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
 #pragma unroll
   for (int j = 0; j < SMALL_EPT; ++j)
     if (tid + 256 * j < n) se += expf(xv[j] - vmax);
-  se = wave_sum(se);
+  se = wave_sum_dpp(se);
   if (lane == 0) sh.wsum[wave] = se;
   // this thread's CONTIGUOUS chunk of keys into registers (index order matters for ties)
   const int ept = (n + 255) / 256;
@@ -1584,11 +1593,8 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     int packed = n1 | (n2 << 10);  // each count <= 17 per thread, <= 1088 per wave: 10 bits are not enough
     // (pack only two 16-bit fields)
     packed = n1 | (n2 << 16);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      packed += __shfl_xor(packed, o, 64);
-      n3 += __shfl_xor(n3, o, 64);
-    }
+    packed = wave_sum_dpp_i(packed);
+    n3 = wave_sum_dpp_i(n3);
     const int par = step & 1;
     if (lane == 0) {
       sh.hist[par * 16 + wave * 2] = (uint32_t)packed;
