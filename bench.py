@@ -26,6 +26,11 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+# HBM bytes fetched per decode frame at batch 8, from the separate rocprofv3 --pmc FETCH_SIZE pass
+# (profiles/r01_pmc_fetch_decode.txt; KiB x 1024 x 2 = the gfx950 correction of MI355X_MICROARCH.md).
+# PMC counters cannot be collected inside a timed run, so the figure is carried here with its provenance.
+PMC_FETCH_BYTES_PER_FRAME = 16.125e9
+
 FRAME_LEN = 2048          # samples per frame (modded_dac.py:833,861)
 SAMPLE_RATE = 44100
 PROMPT_T = 200
@@ -188,8 +193,12 @@ def main():
 
         dist.init_process_group("nccl", device_id=device)
 
+    # the library ships prebuilt in-tree; if it is stale only one process per node compiles it
     from fish_speech_amd.build import build
-    build(verbose=(rank == 0))
+    if local_rank == 0:
+        build(verbose=(rank == 0))
+    if dist:
+        dist.barrier()
     from fish_speech_amd.dual_ar import MiDualAR
 
     globals()["N_FRAMES"] = args.frames
@@ -278,8 +287,10 @@ def main():
         "breakdown_ms": {"decode_frame_avg": round(avg_frame_s * 1e3, 4), "launches_per_frame": launches,
                          "codec_decode_batch": round(sum(codec_ms) / len(codec_ms), 2) if codec_ms else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(achieved / 8000.0, 4), "traffic": None,
-                     "kernel": "decode frame = 314 linear_skinny_kernel launches + attention/sampler (one hipGraph)",
+                     "frac": round(achieved / 8000.0, 4),
+                     "traffic": PMC_FETCH_BYTES_PER_FRAME if (N_FRAMES == 215 and BATCH == 8) else None,
+                     "kernel": "decode frame: 311 linear_skinny_kernel launches (weight streaming) + 36 attention, 40 fast-attention, "
+                               "10 sampler launches, replayed as one hipGraph",
                      "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

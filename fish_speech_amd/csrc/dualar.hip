@@ -64,7 +64,8 @@ struct fmi_dualar {
   void* staging = nullptr;
   size_t staging_bytes = 0;
   float last_ms = 0.f;
-  int launches = 0;  // counted while building one frame
+  int launches = 0;        // counted while building the current eager sequence
+  int frame_launches = 0;  // kernel launches of one decode frame (set whenever a frame is built)
 };
 
 namespace {
@@ -344,7 +345,9 @@ int decode_frame(fmi_dualar* h, int B, hipStream_t s, bool head_only = false) {
   for (int i = 0; i < c.n_layer; ++i)
     FMI_CHECK(block_slow(h, h->L[i], i, h->ws.x, B, h->ws.row_slot, nullptr, s));
   if (head_only) return tail_head(h, h->ws.x, B, s);
-  return tail(h, h->ws.x, B, h->ws.row_slot, s);
+  FMI_CHECK(tail(h, h->ws.x, B, h->ws.row_slot, s));
+  h->frame_launches = h->launches;
+  return FMI_OK;
 }
 
 int reserve_pages(fmi_dualar* h, int slot, int upto_pos_exclusive) {
@@ -754,7 +757,7 @@ int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_fra
   float t = 0.f;
   FMI_CHECK_HIP(hipEventElapsedTime(&t, h->ev_t0, h->ev_t1));
   if (ms) *ms = t;
-  if (launches_per_frame) *launches_per_frame = h->launches;
+  if (launches_per_frame) *launches_per_frame = h->frame_launches;
   return FMI_OK;
 }
 
