@@ -138,3 +138,25 @@ def test_config0_3s_clip_encode_decode_vs_oracle(full):
     assert rms(wav, want) <= 1e-4
     z = codec.debug_z(1)
     assert torch.equal(codec.decode(z), wav)
+
+
+def test_codec_edge_cases_and_misuse(small):
+    from fish_speech_amd import FishmiError
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg, state, z, codec = small
+    one = D.make_codes(cfg, 1, 1, seed=1)
+    wav = codec.from_indices(one.clone().to(DEV))
+    assert wav.shape == (1, 1, cfg.frame_length)
+    assert rms(wav, D.DacOracle(cfg, state).from_indices(one.clone())) <= 1e-4
+    with pytest.raises(ValueError):  # wrong number of codebooks
+        codec.from_indices(torch.zeros(1, cfg.n_codebooks, 3, dtype=torch.int64, device=DEV))
+    with pytest.raises(FishmiError):  # decode before weights
+        MiDAC(DacConfig.from_any(cfg), device=DEV).from_indices(one.clone().to(DEV))
+    with pytest.raises(FishmiError):  # no CPU fallback
+        MiDAC(DacConfig.from_any(cfg), device="cpu")
+    # int32 / non-contiguous indices are accepted like any torch module would (converted, clamp copied back)
+    idx32 = D.make_codes(cfg, 2, 4, seed=2).to(torch.int32)
+    a = codec.from_indices(idx32.to(DEV))
+    b = codec.from_indices(idx32.to(torch.int64).to(DEV))
+    assert torch.equal(a, b)

@@ -392,3 +392,82 @@ def test_reference_decode_function_over_hip_model_equals_hip_step(case, top_k):
             window[:, -1] = want.int()
         cur, pos = want.view(1, ncb1, 1).long(), torch.tensor([T + f])
     assert n_same == 12
+
+
+# ------------------------------------------------------------------------------- edge cases / misuse
+
+
+@pytest.mark.parametrize("T", [1, 63, 64, 65, 130])
+def test_prompt_lengths_around_kv_page_boundaries_vs_oracle(T):
+    """KV pages hold 64 tokens: prompts of 1, 63, 64, 65 and 130 tokens (0, 1 and 2 page crossings, then
+    decode frames that cross the next boundary) against the oracle run on this box: logits within the
+    bf16 noise bound at every frame, tokens equal wherever the oracle's margin allows."""
+    cfg, state, z = load_dualar_case("tiny")
+    model = _make_model(cfg, state)
+    prompt = O.make_prompt(cfg, T, seed=T, n_semantic=min(T // 2, 20))
+    orc = O.DualAROracle(cfg, state)
+    orc.trace = {}
+    n_new = 5
+    seq = O.generate(orc, prompt, n_new, 0.7, 0.7, 1, uniform_fn=O.FmiUniform(99, 0), stop_on_im_end=False)
+    ids = torch.from_numpy(z["live_ids"]).long()
+    ncb1 = cfg.num_codebooks + 1
+    window = torch.zeros(ncb1, 10, dtype=torch.int32)
+    for f in range(n_new):
+        if f == 0:
+            x, pos0, prev = prompt.t().int().contiguous(), 0, None
+        else:
+            x, pos0, prev = seq[:, T + f - 1].view(1, ncb1).int().contiguous(), T + f - 1, window.clone()
+        sp = model._sampling(0.7, 0.7, 1, 99, prev is not None)
+        model.step(x.to(DEV), pos0, sp, prev.to(DEV) if prev is not None else None, f)
+        logits, _, hidden, _ = model.debug_taps(1)
+        want = orc.trace["slow_logits"][f][ids].float()
+        rel = float((logits[0].float().cpu() - want).norm() / want.norm())
+        assert rel <= 2e-2, f"T={T} frame {f}: relative L2 error {rel:.4f}"
+        if f > 0:
+            window = window.roll(-1, dims=1)
+            window[:, -1] = seq[:, T + f].int()
+
+
+def test_single_frame_and_full_length_generation():
+    from fish_speech_amd.dual_ar import generate
+
+    cfg, state, _ = load_dualar_case("tiny")
+    model = _make_model(cfg, state)
+    model.set_ignore_eos(True)
+    p = O.make_prompt(cfg, 9, seed=3)
+    one = generate(model=model, prompt=p, max_new_tokens=1, top_k=1, temperature=0.7, top_p=0.7, seed=5)
+    assert one.shape == (cfg.num_codebooks + 1, 10)  # only the prefill frame (inference.py:336-347 with n-1 = 0)
+    # max_new_tokens = 0 means "fill up to max_seq_len" (inference.py:276-278)
+    full = generate(model=model, prompt=p, max_new_tokens=0, top_k=1, temperature=0.7, top_p=0.7, seed=5,
+                    stop_on_im_end=False)
+    assert full.shape[1] == cfg.max_seq_len
+    assert torch.equal(full[:, :10], one)
+    # a prompt of max_seq_len - 1 tokens can still produce exactly one frame
+    p2 = O.make_prompt(cfg, cfg.max_seq_len - 1, seed=4)
+    out = generate(model=model, prompt=p2, max_new_tokens=50, top_k=1, temperature=0.7, top_p=0.7, seed=5)
+    assert out.shape[1] == cfg.max_seq_len
+
+
+def test_c_abi_misuse_raises_instead_of_crashing():
+    from fish_speech_amd import FishmiError
+    from fish_speech_amd.dual_ar import MiDualAR, generate_batch
+
+    cfg, state, _ = load_dualar_case("tiny")
+    bare = MiDualAR(cfg, device=DEV, im_end_id=cfg.im_end_id)
+    bare.setup_caches(1, cfg.max_seq_len)
+    with pytest.raises(FishmiError):  # weights never loaded
+        bare.prefill([0], [O.make_prompt(cfg, 4, 1)], [4], [bare._sampling(0.7, 0.7, 1, 0)])
+    model = _make_model(cfg, state, max_batch=2)
+    with pytest.raises(FishmiError):  # slot outside the cache
+        model.prefill([5], [O.make_prompt(cfg, 4, 1)], [4], [model._sampling(0.7, 0.7, 1, 0)])
+    with pytest.raises(ValueError):   # more utterances than slots
+        generate_batch(model=model, prompts=[O.make_prompt(cfg, 4, i) for i in range(3)], max_new_tokens=2)
+    with pytest.raises(FishmiError):  # wrong tensor shape at load time
+        bad = dict(state)
+        bad["layers.0.attention.wo.weight"] = bad["layers.0.attention.wo.weight"][:-16]
+        MiDualAR.from_state_dict(cfg, bad, device=DEV, im_end_id=cfg.im_end_id)
+    with pytest.raises(FishmiError):  # a tensor missing at finalize
+        miss = {k: v for k, v in state.items() if k != "fast_norm.weight"}
+        MiDualAR.from_state_dict(cfg, miss, device=DEV, im_end_id=cfg.im_end_id)
+    with pytest.raises(FishmiError):  # no CPU fallback
+        MiDualAR(cfg, device="cpu", im_end_id=cfg.im_end_id)
