@@ -413,7 +413,8 @@ int run_convnext(fmi_dac* h, const ConvNeXt& c, float* x, int B, int C, int T) {
 }
 
 // Decoder (modded_dac.py:760-801) on z = X [B][latent][len]; Y = scratch of the peak size
-int run_decoder(fmi_dac* h, float* X, float* Y, int B, int len, float* audio_out_dev) {
+// skip_cols: leading latent columns whose audio is not written (left context of an incremental decode)
+int run_decoder(fmi_dac* h, float* X, float* Y, int B, int len, float* audio_out_dev, int skip_cols = 0) {
   const fmi_dac_config& c = h->cfg;
   int l2;
   FMI_CHECK(run_conv(h, h->dec_in, X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
@@ -424,8 +425,10 @@ int run_decoder(fmi_dac* h, float* X, float* Y, int B, int len, float* audio_out
     len = l2;
     for (int r = 0; r < 3; ++r) FMI_CHECK(run_res_unit(h, db.ru[r], X, Y, B, len));
   }
+  int hop = 1;
+  for (int i = 0; i < 4; ++i) hop *= c.decoder_rates[i];
   return launch_final_conv_tanh(X, h->dec_alpha, h->final_w, h->final_b, audio_out_dev, B, c.decoder_dim >> 4, len,
-                                h->stream);
+                                skip_cols * hop, h->stream);
 }
 
 int64_t decode_peak_elems(const fmi_dac_config& c, int T) {
@@ -437,6 +440,47 @@ int64_t decode_peak_elems(const fmi_dac_config& c, int T) {
     peak = std::max(peak, (int64_t)(c.decoder_dim >> (i + 1)) * L);
   }
   return peak;
+}
+
+// Left context, in latent columns, after which a decoder output no longer depends on what preceded the cropped
+// input: walk the decoder backwards (final k7 conv; per block three ResidualUnits k7 dil 1/3/9 and the
+// k=2s transposed conv, which reads x[q] and x[q-1]; first k7 conv).  19 columns for rates (8,8,4,2).
+int decoder_context_cols(const fmi_dac_config& c) {
+  int ctx = 6;
+  for (int i = 3; i >= 0; --i) {
+    ctx += 6 * (1 + 3 + 9);
+    ctx = cdiv(ctx, c.decoder_rates[i]) + 1;
+  }
+  return ctx + 6;
+}
+
+// quantizer.decode (rvq.py:352-366) for T frames; z ends up in h->buf[5] [B][latent][4T]
+int run_quantizer_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float** Xp, float** Yp, int* len_p) {
+  const fmi_dac_config& c = h->cfg;
+  const int L0 = c.latent_dim;
+  hipStream_t s = h->stream;
+  const int64_t peak = (int64_t)B * decode_peak_elems(c, T);
+  FMI_CHECK(ensure_buf(h, 0, peak));
+  FMI_CHECK(ensure_buf(h, 1, peak));
+  float *X = h->buf[0].p, *Y = h->buf[1].p;
+  FMI_CHECK(launch_clamp_indices(indices_dev, B, c.n_codebooks + 1, T, c.semantic_codebook_size, c.codebook_size, s));
+  FMI_CHECK(launch_lut_decode(indices_dev, h->lut, h->lut_off, c.n_codebooks, c.semantic_codebook_size, c.codebook_size,
+                              X, B, L0, T, s));
+  FMI_CHECK(run_transformer(h, h->post, X, X, B, T));
+  int len = T;
+  for (int i = 0; i < 2; ++i) {
+    int l2;
+    FMI_CHECK(run_conv(h, h->up_conv[i], X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
+    std::swap(X, Y);
+    len = l2;
+    FMI_CHECK(run_convnext(h, h->up_cnx[i], X, B, L0, len));
+  }
+  // z must survive the decoder (debug tap, incremental decode): keep a copy in buffer 5
+  FMI_CHECK(ensure_buf(h, 5, (int64_t)B * L0 * len));
+  FMI_CHECK_HIP(hipMemcpyAsync(h->buf[5].p, X, (size_t)B * L0 * len * 4, hipMemcpyDeviceToDevice, s));
+  h->last_z = h->buf[5].p; h->last_zC = L0; h->last_zL = len;
+  *Xp = X; *Yp = Y; *len_p = len;
+  return FMI_OK;
 }
 
 }  // namespace
@@ -590,33 +634,35 @@ int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_
   FMI_REQUIRE(h && indices_dev && audio_out_dev, "null argument");
   FMI_REQUIRE(h->ready, "codec weights not ready");
   FMI_REQUIRE(B >= 1 && T >= 1, "empty input");
+  FMI_CHECK(sync_in(h, stream));
+  float *X, *Y;
+  int len;
+  FMI_CHECK(run_quantizer_decode(h, indices_dev, B, T, &X, &Y, &len));
+  FMI_CHECK(run_decoder(h, X, Y, B, len, audio_out_dev));
+  return sync_out(h, stream);
+}
+
+int fmi_dac_context_frames(const fmi_dac* h) { return h ? cdiv(decoder_context_cols(h->cfg), 4) : 0; }
+
+int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, float* audio_out_dev, void* stream) {
+  FMI_REQUIRE(h && indices_dev && audio_out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "codec weights not ready");
+  FMI_REQUIRE(B >= 1 && T >= 1 && t0 >= 0 && t0 < T, "bad frame range [%d, %d)", t0, T);
   const fmi_dac_config& c = h->cfg;
   const int L0 = c.latent_dim;
   FMI_CHECK(sync_in(h, stream));
   hipStream_t s = h->stream;
-  const int64_t peak = (int64_t)B * decode_peak_elems(c, T);
-  FMI_CHECK(ensure_buf(h, 0, peak));
-  FMI_CHECK(ensure_buf(h, 1, peak));
-  float *X = h->buf[0].p, *Y = h->buf[1].p;
-  // quantizer.decode (rvq.py:352-366)
-  FMI_CHECK(launch_clamp_indices(indices_dev, B, c.n_codebooks + 1, T, c.semantic_codebook_size, c.codebook_size, s));
-  FMI_CHECK(launch_lut_decode(indices_dev, h->lut, h->lut_off, c.n_codebooks, c.semantic_codebook_size, c.codebook_size,
-                              X, B, L0, T, s));
-  FMI_CHECK(run_transformer(h, h->post, X, X, B, T));
-  int len = T;
-  for (int i = 0; i < 2; ++i) {
-    int l2;
-    FMI_CHECK(run_conv(h, h->up_conv[i], X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
-    std::swap(X, Y);
-    len = l2;
-    FMI_CHECK(run_convnext(h, h->up_cnx[i], X, B, L0, len));
-  }
-  h->last_z = X; h->last_zC = L0; h->last_zL = len;
-  // the debug tap must survive the decoder: keep z in buffer 2..5? it is small -> copy to buf[5]
-  FMI_CHECK(ensure_buf(h, 5, (int64_t)B * L0 * len));
-  FMI_CHECK_HIP(hipMemcpyAsync(h->buf[5].p, X, (size_t)B * L0 * len * 4, hipMemcpyDeviceToDevice, s));
-  h->last_z = h->buf[5].p;
-  FMI_CHECK(run_decoder(h, X, Y, B, len, audio_out_dev));
+  float *X, *Y;
+  int len;
+  // the quantizer side (LUT + 8-layer windowed transformer + x4 upsampler, 5 % of the per-frame work) is
+  // recomputed over all frames so far: its receptive field (layers x window = 1016 frames) covers any utterance
+  FMI_CHECK(run_quantizer_decode(h, indices_dev, B, T, &X, &Y, &len));
+  const int ctx_frames = std::min(t0, cdiv(decoder_context_cols(c), 4));
+  const int col_lo = 4 * (t0 - ctx_frames), w = len - col_lo;
+  // crop z to [col_lo, 4T): rows are (b, channel)
+  FMI_CHECK_HIP(hipMemcpy2DAsync(X, (size_t)w * 4, h->buf[5].p + col_lo, (size_t)len * 4, (size_t)w * 4,
+                                 (size_t)B * L0, hipMemcpyDeviceToDevice, s));
+  FMI_CHECK(run_decoder(h, X, Y, B, w, audio_out_dev, 4 * ctx_frames));
   return sync_out(h, stream);
 }
 

@@ -64,7 +64,8 @@ int launch_clamp_indices(int64_t* idx, int B, int n_books1, int T, int sem_size,
 int launch_build_lut(const float* codebook /*[n][d]*/, const float* w /*[C][d]*/, const float* bias, float* table,
                      int n, int d, int C, hipStream_t s);
 int launch_final_conv_tanh(const float* x /*[B][C][L]*/, const float* alpha, const float* w /*[C][7]*/,
-                           const float* bias, float* out /*[B][1][L]*/, int B, int C, int L, hipStream_t s);
+                           const float* bias, float* out /*[B][1][L-col0]*/, int B, int C, int L, int col0,
+                           hipStream_t s);
 int launch_first_conv(const float* x /*[B][1][L]*/, const float* w /*[C][7]*/, const float* bias, float* out,
                       int B, int C, int L, hipStream_t s);
 struct VqArgs {

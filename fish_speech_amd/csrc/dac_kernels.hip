@@ -90,7 +90,10 @@ int launch_pack_convtr(const float* w_src, float* dst, int cin, int cout, int k,
 
 __device__ inline float snake_f(float v, float alpha) {
   // dac.nn.layers.snake: x + (alpha + 1e-9)^-1 * sin(alpha*x)^2
-  const float sn = sinf(alpha * v);
+  // hardware sine (v_sin_f32 after an exact 1/(2 pi) range reduction): absolute error ~1e-6, far inside the
+  // 1e-4 waveform RMS bar (measured 6e-7 end to end), and ~10x fewer VALU ops than the libm sinf that made
+  // input-tile staging the bottleneck of this kernel
+  const float sn = __sinf(alpha * v);
   return v + (1.0f / (alpha + 1e-9f)) * (sn * sn);
 }
 
@@ -219,6 +222,134 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, i
     }
 }
 
+// Pipelined variant: the weight tile is double-buffered in LDS and the DMA of step c+1 is issued right
+// before the MFMAs of step c; the input-tile elements of step c+1 are fetched into (few) registers at the
+// same point and written to LDS (with Snake) after the MFMAs.  Global latency hides behind the matrix
+// pipe inside one work-group instead of relying on other work-groups.
+constexpr int CONV_XR = 16;  // input-tile elements per thread held across the MFMA phase (CI*wx <= 4096)
+
+template <int MT, int NT, int CI>
+__global__ __launch_bounds__(256) void conv_mfma_pipe_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
+  constexpr int ROWB = CO_T * 4;
+  const int taps = a.w.taps;
+  const int nw = taps * CI * CO_T;
+  float* Wbuf[2] = {smem, smem + nw};
+  float* Xs = smem + 2 * nw;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lk = lane >> 5;
+  const int q0 = blockIdx.x * TT;
+  const int co0 = blockIdx.y * CO_T;
+  const int b = blockIdx.z / a.w.phases, phase = blockIdx.z % a.w.phases;
+  const int c0 = q0 * a.x_stride + a.tap_base - tap_off0;
+  const float* xb = a.x + (int64_t)b * a.w.cin * a.lin;
+  const float* wph = a.w.w + (int64_t)phase * taps * a.w.cin_pad * a.w.cout_pad;
+  const int n_pieces = nw / 256;
+  const bool do_snake = a.snake_alpha != nullptr;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int qw = wave * NT * 32;
+
+  auto dma_w = [&](int ci0, float* dst) {
+    for (int p = wave; p < n_pieces; p += 4) {
+      const int o = p * 1024 + lane * 16;
+      const int row = o / ROWB, cb = o - row * ROWB;
+      const int tp = row / CI, r = row - tp * CI;
+      const char* g = reinterpret_cast<const char*>(wph + ((int64_t)tp * a.w.cin_pad + ci0 + r) * a.w.cout_pad + co0) + cb;
+      __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(reinterpret_cast<char*>(dst) + p * 1024), 16, 0, 0);
+    }
+  };
+  // element u of this thread: row = wave + 4*(u / XPR), column = lane + 64*(u % XPR), XPR = ceil(wx/64)
+  const int xpr = (wx + 63) >> 6;
+  float xr[CONV_XR];
+  auto load_x = [&](int ci0) {
+#pragma unroll
+    for (int u = 0; u < CONV_XR; ++u) {
+      const int rr = u / xpr, cc = u - rr * xpr;
+      const int r = wave + 4 * rr, c = lane + 64 * cc;
+      const int ci = ci0 + r, col = c0 + c;
+      float v = 0.f;
+      if (r < CI && c < wx && ci < a.w.cin && col >= 0 && col < a.lin) v = xb[(int64_t)ci * a.lin + col];
+      xr[u] = v;
+    }
+  };
+  auto store_x = [&](int ci0) {
+#pragma unroll
+    for (int u = 0; u < CONV_XR; ++u) {
+      const int rr = u / xpr, cc = u - rr * xpr;
+      const int r = wave + 4 * rr, c = lane + 64 * cc;
+      if (r < CI && c < wx) {
+        float v = xr[u];
+        const int ci = ci0 + r;
+        if (do_snake && ci < a.w.cin) v = snake_f(v, a.snake_alpha[ci]);
+        Xs[r * wx + c] = v;
+      }
+    }
+  };
+
+  dma_w(0, Wbuf[0]);
+  load_x(0);
+  int cur = 0;
+  for (int ci0 = 0; ci0 < a.w.cin_pad; ci0 += CI) {
+    store_x(ci0);
+    __syncthreads();  // Xs visible; the DMA of this step has landed (barrier fence waits vmcnt(0))
+    const float* Ws = Wbuf[cur];
+    if (ci0 + CI < a.w.cin_pad) {
+      dma_w(ci0 + CI, Wbuf[cur ^ 1]);
+      load_x(ci0 + CI);
+    }
+    for (int tp = 0; tp < taps; ++tp) {
+      const int xoff = tap_off0 + tp * a.tap_step;
+#pragma unroll
+      for (int k2 = 0; k2 < CI / 2; ++k2) {
+        const int row = k2 * 2 + lk;
+        float af[MT], bf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = Ws[(tp * CI + row) * CO_T + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = Xs[row * wx + (qw + j * 32 + li) * a.x_stride + xoff];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // everyone is done reading Xs / Wbuf[cur]
+    cur ^= 1;
+  }
+
+  float* ob = a.out + (int64_t)b * a.w.cout * a.lout;
+  const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : nullptr;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int q = q0 + qw + j * 32 + li;
+      if (q >= ncols) continue;
+      const int col = q * a.out_stride + phase;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co >= a.w.cout) continue;
+        float v = acc[i][j][r];
+        if (a.w.bias) v += a.w.bias[co];
+        if (a.act == ACT_GELU) v = gelu_f(v);
+        if (a.gamma) v *= a.gamma[co];
+        if (rb) v += rb[(int64_t)co * a.lout + col];
+        ob[(int64_t)co * a.lout + col] = v;
+      }
+    }
+}
+
 template <int MT, int NT, int CI>
 static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
   const ConvW& w = a.w;
@@ -230,6 +361,17 @@ static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, h
   // the DMA copies whole CO_T-wide rows: every tile must lie inside the padded weight rows
   const bool dma = allow_dma && (w.cout_pad % CO_T == 0) && (w.cin_pad % CI == 0);
   dim3 grid(cdiv(ncols, TT), cdiv(w.cout_pad, CO_T), a.B * w.phases), block(256);
+  static const bool allow_pipe = []() { const char* e = getenv("FMI_CONV_PIPE"); return !(e && e[0] == '0'); }();
+  const int xpr = (wx + 63) / 64;
+  const size_t smem_pipe = (size_t)(CI * wx + 2 * w.taps * CI * CO_T) * sizeof(float);
+  if (dma && allow_pipe && a.dbg == 0 && (CI / 4) * xpr <= CONV_XR && CI % 4 == 0 && smem_pipe <= 80 * 1024) {
+    if (smem_pipe > 64 * 1024)
+      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_pipe_kernel<MT, NT, CI>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pipe));
+    hipLaunchKernelGGL((conv_mfma_pipe_kernel<MT, NT, CI>), grid, block, smem_pipe, s, a, ncols, wx, tap_off0);
+    FMI_CHECK_HIP(hipGetLastError());
+    return FMI_OK;
+  }
   if (dma) {
     if (smem > 64 * 1024)
       FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, CI, true>,
@@ -266,6 +408,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
 #define FMI_CONV(MT_, NT_)                                                            \
   return k1 ? launch_conv_t<MT_, NT_, 32>(a, ncols, tap_off0, span, s)                \
             : launch_conv_t<MT_, NT_, 8>(a, ncols, tap_off0, span, s)
+  static const bool wide = []() { const char* e = getenv("FMI_CONV_WIDE"); return e && e[0] == '1'; }();  // measured slower
+  if (MT == 4 && wide && ncols >= 2048) FMI_CONV(4, 2);  // 256-column tiles: each staged weight tile feeds 2x the MFMAs
   if (MT == 4) FMI_CONV(4, 1);
   if (MT == 3) FMI_CONV(3, 2);
   if (MT == 2) FMI_CONV(2, 2);
@@ -650,13 +794,15 @@ int launch_first_conv(const float* x, const float* w, const float* bias, float* 
 // Snake(x) is staged once in LDS (each element is used by 7 outputs).
 __global__ __launch_bounds__(256) void final_conv_tanh_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ out, int C, int L) {
+                                                              float* __restrict__ out, int C, int L, int col0) {
+  // columns [col0, L) are produced, packed to rows of L - col0 samples (col0 > 0: the incremental decode drops
+  // the left-context samples; the sum order of a column does not depend on col0, so results are bit-identical)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TT = 256, CC = 32;  // 32 channels x (256 + 6) columns per stage
   float* Xs = smem;                 // [CC][TT + 6]
   float* Wl = smem + CC * (TT + 6); // [CC][7]
   const int tid = threadIdx.x;
-  const int t0 = blockIdx.x * TT, b = blockIdx.y;
+  const int t0 = col0 + blockIdx.x * TT, b = blockIdx.y;
   const float* xb = x + (int64_t)b * C * L;
   float acc = 0.f;
   for (int c0 = 0; c0 < C; c0 += CC) {
@@ -675,13 +821,14 @@ __global__ __launch_bounds__(256) void final_conv_tanh_kernel(const float* __res
     __syncthreads();
   }
   const int t = t0 + tid;
-  if (t < L) out[(int64_t)b * L + t] = tanhf(acc + bias[0]);
+  if (t < L) out[(int64_t)b * (L - col0) + (t - col0)] = tanhf(acc + bias[0]);
 }
 
 int launch_final_conv_tanh(const float* x, const float* alpha, const float* w, const float* bias, float* out, int B,
-                           int C, int L, hipStream_t s) {
+                           int C, int L, int col0, hipStream_t s) {
   const size_t smem = (size_t)(32 * (256 + 6) + 32 * 7) * sizeof(float);
-  hipLaunchKernelGGL(final_conv_tanh_kernel, dim3(cdiv(L, 256), B), dim3(256), smem, s, x, alpha, w, bias, out, C, L);
+  hipLaunchKernelGGL(final_conv_tanh_kernel, dim3(cdiv(L - col0, 256), B), dim3(256), smem, s, x, alpha, w, bias, out,
+                     C, L, col0);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }

@@ -289,6 +289,28 @@ class MiDAC:
         self._keep = work
         return out
 
+    # ---- incremental decode for streaming: audio of frames [t0, T) given all codes so far.  Bit-identical to
+    # from_indices(final codes)[..., t0*frame_length : T*frame_length] because every codec layer is causal
+    # (modded_dac.py:521-588; window mask 380-398).  `indices` is clamped in place like from_indices.
+    @torch.no_grad()
+    def from_indices_tail(self, indices: torch.Tensor, t0: int) -> torch.Tensor:
+        work = indices.to(device=self.device, dtype=torch.int64).contiguous()
+        B, nb, T = work.shape
+        if nb != self.config.n_codebooks + 1:
+            raise ValueError(f"expected {self.config.n_codebooks + 1} codebooks, got {nb}")
+        if not 0 <= t0 < T:
+            raise ValueError(f"t0={t0} outside [0, {T})")
+        out = torch.empty(B, 1, (T - t0) * self.frame_length, dtype=torch.float32, device=self.device)
+        check(self.lib.fmi_dac_decode_tail(self._h, C.c_void_p(work.data_ptr()), B, T, int(t0),
+                                           C.c_void_p(out.data_ptr()), self._stream()))
+        self._keep = work
+        return out
+
+    @property
+    def context_frames(self) -> int:
+        """left context (frames) the decoder conv stack re-reads per incremental call"""
+        return int(self.lib.fmi_dac_context_frames(self._h))
+
     # ---- DAC.decode (modded_dac.py:929-946): latent z (B, latent_dim, L) -> waveform
     @torch.no_grad()
     def decode(self, z: torch.Tensor) -> torch.Tensor:

@@ -209,6 +209,15 @@ int fmi_dac_weights_ready(fmi_dac* h);
  * (rvq.py:354-359) the indices are clamped IN PLACE. */
 int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_out_dev,
                    void* stream);
+/* Incremental decode for streaming (BASELINE config 5; the consumer is the engine's segment streaming,
+ * fish_speech/inference_engine/__init__.py:73-140, which today waits for a whole text chunk): indices
+ * (B,1+n_codebooks,T) = all frames generated so far; writes the audio of frames [t0,T) only,
+ * (B,1,(T-t0)*frame_length), bit-identical to the same samples of fmi_dac_decode over the final utterance
+ * (every codec layer is causal: modded_dac.py:521-588, window mask 380-398).  The decoder conv stack runs on
+ * frames [t0-ctx, T) with ctx = fmi_dac_context_frames() (its receptive field, 5 frames for rates 8,8,4,2). */
+int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, float* audio_out_dev,
+                        void* stream);
+int fmi_dac_context_frames(const fmi_dac* h);
 /* DAC.decode (modded_dac.py:929-946): latent z fp32 (B, latent_dim, L) -> audio fp32 (B,1,L*hop_length). */
 int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* audio_out_dev, void* stream);
 /* DAC.encode (modded_dac.py:874-923): audio fp32 (B,1,N) (N already padded to a multiple of

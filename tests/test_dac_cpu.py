@@ -69,3 +69,38 @@ def test_product_shim_fold_equals_oracle_fold(case):
     cfg, state, _ = case
     a, b = fold_weight_norm(state), D.fold_weight_norm(state)
     assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_decoder_receptive_field_bounds_the_streaming_context():
+    """The incremental decode (fmi_dac_decode_tail) runs the decoder conv stack on frames [t0-ctx, T) and
+    drops the context's samples.  On the restated reference decoder: with ctx = the receptive field computed
+    by the library's formula (19 latent columns -> 5 frames for rates 8,8,4,2; here the small config's) the
+    kept samples equal the full decode's, and with one column less of context they do not."""
+    cfg = D.small_config()
+    state = D.make_synthetic_state(cfg, seed=2)
+    orc = D.DacOracle(cfg, state)
+    ctx = 6
+    for r in reversed(cfg.decoder_rates):
+        ctx = -(-(ctx + 6 * (1 + 3 + 9)) // r) + 1
+    ctx += 6
+    codes = D.make_codes(cfg, 1, 4 + -(-ctx // 4) + 3, seed=4)
+    z = orc.dequantize(codes.clone())
+    full = orc.decoder(z)
+    hop = cfg.hop_length
+    col0 = z.shape[-1] - 8                   # keep the audio of the last 8 latent columns
+    ok = orc.decoder(z[:, :, col0 - ctx:])[..., ctx * hop:]
+    assert torch.allclose(ok, full[..., col0 * hop:], atol=2e-6, rtol=0)
+    short = orc.decoder(z[:, :, col0 - ctx + 1:])[..., (ctx - 1) * hop:]
+    assert not torch.allclose(short, full[..., col0 * hop:], atol=2e-6, rtol=0)
+
+
+def test_stream_chunk_schedule():
+    from fish_speech_amd.stream import chunk_schedule
+
+    assert chunk_schedule(215, 9, 32) == [9, 41, 73, 105, 137, 169, 201, 215]
+    assert chunk_schedule(5, 9, 32) == [5]
+    assert chunk_schedule(9, 9, 4) == [9]
+    assert chunk_schedule(10, 2, 4) == [2, 6, 10]
+    import pytest
+    with pytest.raises(ValueError):
+        chunk_schedule(10, 0, 4)

@@ -1,0 +1,141 @@
+"""Streaming chunked decode (BASELINE.json config 5) on the GPU: what is streamed must be exactly what
+the offline path produces -- codes from ``generate_batch``, audio from ``MiDAC.from_indices`` over the
+final codes (``codes = y[1:, T:-1]``, inference.py:708) -- for any chunking."""
+import pytest
+import torch
+
+from oracle import dac as D
+from tests.helpers import load_dualar_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def small_codec():
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg = D.small_config()
+    state = D.make_synthetic_state(cfg, seed=11)
+    return cfg, state, MiDAC.from_state_dict(DacConfig.from_any(cfg), state, device=DEV)
+
+
+@pytest.fixture(scope="module")
+def full_codec():
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg = D.DacConfig()
+    state = D.make_synthetic_state(cfg, seed=3)
+    return cfg, state, MiDAC.from_state_dict(DacConfig.from_any(cfg), state, device=DEV)
+
+
+def _tail_chunks_equal_full(cfg, codec, B, T, cuts, seed):
+    codes = D.make_codes(cfg, B, T, seed=seed).to(DEV)
+    want = codec.from_indices(codes.clone())
+    fl = cfg.frame_length
+    pieces, t0 = [], 0
+    for t1 in list(cuts) + [T]:
+        got = codec.from_indices_tail(codes[:, :, :t1].clone(), t0)
+        assert got.shape == (B, 1, (t1 - t0) * fl)
+        pieces.append(got)
+        t0 = t1
+    got = torch.cat(pieces, dim=-1)
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def test_tail_decode_concatenates_to_the_full_decode_bitwise_small(small_codec):
+    cfg, _, codec = small_codec
+    assert codec.context_frames >= 1
+    _tail_chunks_equal_full(cfg, codec, 2, 40, [1, 2, 7, 8, 20, 39], seed=1)
+    _tail_chunks_equal_full(cfg, codec, 1, 9, [4], seed=2)
+
+
+def test_tail_decode_concatenates_to_the_full_decode_bitwise_full_size(full_codec):
+    """yaml-sized codec; cuts closer together than the decoder's receptive field (5 frames) and far apart."""
+    cfg, _, codec = full_codec
+    assert codec.context_frames == 5   # 19 latent columns for decoder rates (8, 8, 4, 2)
+    _tail_chunks_equal_full(cfg, codec, 2, 48, [3, 4, 9, 33], seed=4)
+
+
+def test_tail_decode_matches_oracle(full_codec):
+    cfg, state, codec = full_codec
+    codes = D.make_codes(cfg, 1, 12, seed=8)
+    want = D.DacOracle(cfg, state).from_indices(codes.clone())
+    got = codec.from_indices_tail(codes.to(DEV), 7).cpu()
+    ref = want[..., 7 * cfg.frame_length:]
+    assert float((got - ref).pow(2).mean().sqrt()) <= 1e-4
+
+
+def test_tail_rejects_bad_ranges(small_codec):
+    cfg, _, codec = small_codec
+    codes = D.make_codes(cfg, 1, 6, seed=3).to(DEV)
+    for t0 in (-1, 6, 9):
+        with pytest.raises((ValueError, RuntimeError)):
+            codec.from_indices_tail(codes.clone(), t0)
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR
+
+    cfg, state, z = load_dualar_case("tiny")
+    model = MiDualAR.from_state_dict(DualARConfig.from_any(cfg), state, device=DEV, im_end_id=cfg.im_end_id)
+    model.setup_caches(4, cfg.max_seq_len)
+    return cfg, model
+
+
+def _prompts(cfg, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        T = 5 + 3 * i
+        p = torch.zeros(cfg.num_codebooks + 1, T, dtype=torch.int64)
+        p[0] = torch.randint(0, cfg.semantic_begin_id, (T,), generator=g)
+        out.append(p)
+    return out
+
+
+@pytest.mark.parametrize("ignore_eos", [True, False])
+@pytest.mark.parametrize("first,chunk", [(1, 1), (3, 5), (8, 32)])
+def test_stream_equals_offline_codes_and_audio(tiny_model, small_codec, ignore_eos, first, chunk):
+    """Sampled generation (temperature 0.9, top-p 0.8, top-k 20, RAS on) of a ragged batch of three, streamed
+    vs. offline: identical codes, bit-identical audio, per utterance, whatever the chunk sizes.  With EOS live
+    the utterances end at different frames (or at max_new_tokens)."""
+    from fish_speech_amd.dual_ar import generate_batch
+    from fish_speech_amd.stream import generate_stream
+
+    cfg, model = tiny_model
+    ccfg, _, codec = small_codec
+    assert cfg.num_codebooks == ccfg.n_codebooks + 1
+    model.set_ignore_eos(ignore_eos)
+    prompts = _prompts(cfg, 3, seed=5)
+    kw = dict(temperature=0.9, top_p=0.8, top_k=20, seeds=[101, 102, 103])
+    n_new = 24
+    offline = generate_batch(model=model, prompts=prompts, max_new_tokens=n_new, **kw)
+    audio = [[] for _ in prompts]
+    codes = [[] for _ in prompts]
+    marks = []
+    for ch in generate_stream(model=model, codec=codec, prompts=prompts, max_new_tokens=n_new,
+                              first_chunk_frames=first, chunk_frames=chunk, **kw):
+        marks.append((ch.t0, ch.t1))
+        assert ch.audio.shape[-1] == (ch.t1 - ch.t0) * ccfg.frame_length
+        for i, v in enumerate(ch.valid_frames):
+            if v:
+                audio[i].append(ch.audio[i, :, : v * ccfg.frame_length])
+                codes[i].append(ch.codes[i, :, :v])
+    assert marks[0] == (0, min(first, n_new - 1)) or not ignore_eos
+    assert all(a[1] == b[0] for a, b in zip(marks, marks[1:]))
+    lengths = []
+    for i, p in enumerate(prompts):
+        want_codes = offline[i][1:, p.shape[1]:-1].to(DEV)       # inference.py:708
+        lengths.append(want_codes.shape[1])
+        got_codes = torch.cat(codes[i], dim=1) if codes[i] else want_codes[:, :0]
+        assert torch.equal(got_codes, want_codes), i
+        if want_codes.shape[1] == 0:
+            assert not audio[i]
+            continue
+        want_audio = codec.from_indices(want_codes[None].clone())[0]
+        assert torch.equal(torch.cat(audio[i], dim=-1), want_audio), i
+    if ignore_eos:
+        assert lengths == [n_new - 1] * 3
+    model.set_ignore_eos(False)
