@@ -580,7 +580,7 @@ int fmi_dac_load_tensor(fmi_dac* h, const char* name_c, const float* src, int nd
                               s.cout_pad, st);
       break;
     case K_CONV_PART:  // rows [co_off, co_off+cout) of a stacked k=1 weight; padding stays zero (arena memset)
-      rc = launch_pack_conv_part(dsrc, s.dst, (int)s.dims[0], (int)s.dims[1], s.cout_pad, s.co_off, st);
+      rc = launch_pack_conv_part(dsrc, s.dst, (int)s.dims[0], (int)s.dims[1], s.cin_pad, s.cout_pad, s.co_off, st);
       break;
   }
   FMI_CHECK(rc);

@@ -6,7 +6,8 @@
 namespace fmi {
 
 // Packed weight layout of one conv / linear / transposed conv, built at load time:
-//   w[phase][tap][ci_pad][co_pad]  (zero padded; ci_pad % 8 == 0, co_pad % 32 == 0)
+//   w[phase][tap][ci_pad/8][co_pad][8]  (zero padded; ci_pad % 8 == 0, co_pad % 32 == 0; the two 16-byte
+//   halves of a [8] row are swapped on rows co with bit 3 set -- conv_w_index in dac_kernels.hip)
 // regular conv:      phases = 1, taps = K
 // transposed (k=2s): phases = s, taps = 2   (tap m reads x[q - m], weight index j + m*s)
 // transposed (k=s):  phases = s, taps = 1
@@ -32,7 +33,6 @@ struct ConvArgs {
   int tap_base;         // input column of tap 0 for output column 0 (= -(left pad); 0 for transposed)
   int out_stride;       // output column step per computed column (1; stride for transposed)
   int act;
-  int dbg;              // profiling only: 1 = skip LDS staging, 2 = skip MFMAs, 3 = skip Snake
 };
 // out[b][co][q*out_stride + phase] = res + gamma * act(bias + sum_ci sum_tap w[phase][tap][ci][co] *
 //                                    snake(x)[b][ci][q*x_stride + tap_base + tap*tap_step])
@@ -41,8 +41,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 // weight re-layouts (run once at load)
 int launch_pack_conv(const float* w_src /*[cout][cin][k]*/, float* dst, int cout, int cin, int k, int cin_pad,
                      int cout_pad, hipStream_t s);
-int launch_pack_conv_part(const float* w_src /*[cout][cin]*/, float* dst, int cout, int cin, int cout_pad, int co_off,
-                          hipStream_t s);
+int launch_pack_conv_part(const float* w_src /*[cout][cin]*/, float* dst, int cout, int cin, int cin_pad, int cout_pad,
+                          int co_off, hipStream_t s);
 int launch_pack_convtr(const float* w_src /*[cin][cout][k]*/, float* dst, int cin, int cout, int k, int stride,
                        int cin_pad, int cout_pad, hipStream_t s);
 

@@ -20,8 +20,17 @@
 namespace fmi {
 
 // =====================================================================================
-// weight packing: w[phase][tap][ci_pad][co_pad]
+// weight packing: w[phase][tap][ci_pad/8][co_pad][8]
 // =====================================================================================
+// One (tap, 8-channel group) of a 32*MT-row tile is a contiguous block of MT KiB, so the LDS-DMA copies it
+// in linear 1 KiB pieces, and the 8 channels of one output row are adjacent: a lane fetches the four
+// reduction steps of its MFMA A operand with ONE ds_read_b128.  The two 16-byte halves of a row (channels
+// 0-3 / 4-7) are swapped on rows with bit 3 set, which makes those reads bank-conflict free (ds_read_b128 is
+// serviced in 16-lane groups that must cover 64 distinct banks; MI355X_MICROARCH.md LDS table).
+__host__ __device__ inline int64_t conv_w_index(int tapg, int ci, int co, int cin_pad, int cout_pad) {
+  return ((((int64_t)tapg * (cin_pad >> 3) + (ci >> 3)) * cout_pad + co) << 3) +
+         ((((ci >> 2) ^ (co >> 3)) & 1) << 2) + (ci & 3);
+}
 
 __global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
                                  int cin_pad, int cout_pad) {
@@ -32,7 +41,7 @@ __global__ void pack_conv_kernel(const float* __restrict__ src, float* __restric
     const int tap = (int)(i / ((int64_t)cout_pad * cin_pad));
     float v = 0.f;
     if (co < cout && ci < cin) v = src[((int64_t)co * cin + ci) * k + tap];
-    dst[i] = v;
+    dst[conv_w_index(tap, ci, co, cin_pad, cout_pad)] = v;
   }
 }
 
@@ -43,23 +52,25 @@ int launch_pack_conv(const float* w_src, float* dst, int cout, int cin, int k, i
   return FMI_OK;
 }
 
-// rows [co_off, co_off + cout) of a stacked k=1 weight: dst[ci][co_off + co] = src[co][ci]; nothing else is touched
+// rows [co_off, co_off + cout) of a stacked k=1 weight (src [cout][cin]); nothing else is touched
 __global__ void pack_conv_part_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin,
-                                      int cout_pad, int co_off) {
+                                      int cin_pad, int cout_pad, int co_off) {
   const int64_t total = (int64_t)cout * cin;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int co = (int)(i % cout), ci = (int)(i / cout);
-    dst[(int64_t)ci * cout_pad + co_off + co] = src[(int64_t)co * cin + ci];
+    dst[conv_w_index(0, ci, co_off + co, cin_pad, cout_pad)] = src[(int64_t)co * cin + ci];
   }
 }
 
-int launch_pack_conv_part(const float* w_src, float* dst, int cout, int cin, int cout_pad, int co_off, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv_part_kernel, dim3(1024), dim3(256), 0, s, w_src, dst, cout, cin, cout_pad, co_off);
+int launch_pack_conv_part(const float* w_src, float* dst, int cout, int cin, int cin_pad, int cout_pad, int co_off,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_part_kernel, dim3(1024), dim3(256), 0, s, w_src, dst, cout, cin, cin_pad, cout_pad,
+                     co_off);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
 
-// ConvTranspose1d weight [cin][cout][k], stride s, k = taps*s:  dst[phase j][tap m][ci][co] = w[ci][co][j + m*s]
+// ConvTranspose1d weight [cin][cout][k], stride s, k = taps*s:  w[phase j][tap m][ci][co] = src[ci][co][j + m*s]
 __global__ void pack_convtr_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int k,
                                    int stride, int cin_pad, int cout_pad) {
   const int taps = k / stride;
@@ -71,7 +82,7 @@ __global__ void pack_convtr_kernel(const float* __restrict__ src, float* __restr
     const int j = (int)(i / ((int64_t)cout_pad * cin_pad * taps));
     float v = 0.f;
     if (co < cout && ci < cin) v = src[((int64_t)ci * cout + co) * k + j + m * stride];
-    dst[i] = v;
+    dst[conv_w_index(j * taps + m, ci, co, cin_pad, cout_pad)] = v;
   }
 }
 
@@ -89,44 +100,45 @@ int launch_pack_convtr(const float* w_src, float* dst, int cin, int cout, int k,
 // =====================================================================================
 
 __device__ inline float snake_f(float v, float alpha) {
-  // dac.nn.layers.snake: x + (alpha + 1e-9)^-1 * sin(alpha*x)^2
-  // hardware sine (v_sin_f32 after an exact 1/(2 pi) range reduction): absolute error ~1e-6, far inside the
-  // 1e-4 waveform RMS bar (measured 6e-7 end to end), and ~10x fewer VALU ops than the libm sinf that made
-  // input-tile staging the bottleneck of this kernel
+  // dac.nn.layers.snake: x + (alpha + 1e-9)^-1 * sin(alpha*x)^2.  Hardware sine (v_sin_f32 after the 1/(2 pi)
+  // range reduction): absolute error ~1e-6, far inside the 1e-4 waveform RMS bar (5e-7 measured end to end).
   const float sn = __sinf(alpha * v);
   return v + (1.0f / (alpha + 1e-9f)) * (sn * sn);
 }
 
 __device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// CI input channels are staged per step (8 for multi-tap convs, 32 for k = 1 where a step holds
-// almost no math).  Staging was the bottleneck of the first version (ablation in profiles/): so
-//   * the weight tile goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction
-//     moves 1 KiB, no VGPR round trip, no VALU); the packed layout [tap][ci][co_pad] makes every tile
-//     row contiguous, the LDS image is the lane-linear copy the DMA requires;
-//   * the input tile is staged with division-free indexing: a wave owns whole channel rows, lanes run
-//     along time (coalesced), Snake is applied on the way into LDS.
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int MT, int NT, int CI, bool DMA>
+// Work-group = 4 waves; output tile = (MT*32 channels) x (4 waves * NT*32 columns); every wave multiplies the
+// whole weight tile with its own columns.  Per step G groups of 8 input channels are staged:
+//   Ws [taps][G][CO_T][8]  by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR/VALU)
+//   Xs [G][wx][8]          input columns x 8 channels, Snake applied on the way in, 16-byte writes
+// both with the half-swap described at conv_w_index.  The MFMA loop then needs (MT + NT) ds_read_b128 per
+// 4*MT*NT v_mfma_f32_32x32x2_f32: the first version of this kernel (b32 operand reads, rolled loop, 11 other
+// instructions per MFMA) was bound by the SIMD's instruction issue, not by the matrix pipe or the LDS
+// (profiles/r01_pmc_conv.txt).  Reduction step s of a group pairs channels (s, 4+s): lane half 0 / 1.
+template <int MT, int NT, int G>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
-  constexpr int ROWB = CO_T * 4;  // bytes per weight-tile row
-  float* Ws = smem;                        // [taps][CI][CO_T]  (first: 16-byte aligned for the DMA)
   const int taps = a.w.taps;
-  const int nw = taps * CI * CO_T;
-  float* Xs = smem + nw;                   // [CI][wx]
+  float* Ws = smem;                           // first: 1 KiB-aligned pieces for the DMA
+  const int nw = taps * G * CO_T * 8;
+  float* Xs = smem + nw;
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile bookkeeping stays on the SALU
   const int li = lane & 31, lk = lane >> 5;
   const int q0 = blockIdx.x * TT;
   const int co0 = blockIdx.y * CO_T;
   const int b = blockIdx.z / a.w.phases, phase = blockIdx.z % a.w.phases;
   const int c0 = q0 * a.x_stride + a.tap_base - tap_off0;  // input column of LDS column 0
   const float* xb = a.x + (int64_t)b * a.w.cin * a.lin;
-  const float* wph = a.w.w + (int64_t)phase * taps * a.w.cin_pad * a.w.cout_pad;
+  const int cgs = a.w.cin_pad >> 3;
+  const float* wph = a.w.w + (((int64_t)phase * taps * cgs * a.w.cout_pad + co0) << 3);
+  const bool do_snake = a.snake_alpha != nullptr;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -136,63 +148,74 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int qw = wave * NT * 32;  // this wave's first column inside the tile
-  const int n_pieces = nw / 256;  // 1 KiB pieces of the weight tile (CI*CO_T*4 is a multiple of 1 KiB)
+  const int qw = wave * NT * 32;       // this wave's first column inside the tile
+  const int n_rows = taps * G;         // (tap, group) rows of the weight tile, MT KiB each
+  const int nblk = (wx + 63) >> 6;     // 64-column blocks of the input tile
+  // A operand: row li of 32-row block i, half lk (swapped on rows with bit 3 set)
+  const char* a_lane = reinterpret_cast<const char*>(Ws) + li * 32 + (((lk ^ (li >> 3)) & 1) << 4);
 
-  for (int ci0 = 0; ci0 < a.w.cin_pad; ci0 += CI) {
-    // ---- weight tile
-    if (DMA) {
-      for (int p = wave; p < n_pieces; p += 4) {
-        const int o = p * 1024 + lane * 16;         // byte offset inside the tile == inside LDS
-        const int row = o / ROWB, cb = o - row * ROWB;  // row = tap * CI + r
-        const int tp = row / CI, r = row - tp * CI;
-        const char* g = reinterpret_cast<const char*>(wph + ((int64_t)tp * a.w.cin_pad + ci0 + r) * a.w.cout_pad + co0) + cb;
-        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(reinterpret_cast<char*>(Ws) + p * 1024), 16, 0, 0);
-      }
-    } else {
-      for (int e = tid; e < nw; e += 256) {
-        const int i = e % CO_T, r = (e / CO_T) % CI, tp = e / (CO_T * CI);
-        float v = 0.f;
-        if (co0 + i < a.w.cout_pad) v = wph[((int64_t)tp * a.w.cin_pad + ci0 + r) * a.w.cout_pad + co0 + i];
-        Ws[e] = v;
-      }
+  for (int cg0 = 0; cg0 < cgs; cg0 += G) {
+    // ---- weight tile: row = tap*G + g, MT pieces of 1 KiB per row, pieces dealt round-robin to the waves
+    for (int p = wave; p < n_rows * MT; p += 4) {
+      const int row = p / MT, pc = p - row * MT;
+      const int tp = row / G, g = row - tp * G;
+      const char* gsrc = reinterpret_cast<const char*>(wph + (((int64_t)tp * cgs + cg0 + g) * a.w.cout_pad << 3)) +
+                         pc * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)(reinterpret_cast<char*>(Ws) + p * 1024), 16, 0, 0);
     }
-    // ---- input tile (Snake fused): wave w stages rows w, w+4, ...; lanes along time
-    if (a.dbg != 1) {
-      for (int r = wave; r < CI; r += 4) {
-        const int ci = ci0 + r;
-        const bool crow = ci < a.w.cin;
-        const float* xr = xb + (int64_t)(crow ? ci : 0) * a.lin;
-        const float alpha = (crow && a.snake_alpha && a.dbg != 3) ? a.snake_alpha[ci] : 0.f;
-        const bool do_snake = a.snake_alpha && a.dbg != 3;
-        for (int c = lane; c < wx; c += 64) {
-          const int col = c0 + c;
-          float v = 0.f;
-          if (crow && col >= 0 && col < a.lin) {
-            v = xr[col];
-            if (do_snake) v = snake_f(v, alpha);
+    // ---- input tile: a wave takes (group, half, 64-column block) items; lanes run along time (coalesced)
+    for (int it = wave; it < 2 * G * nblk; it += 4) {
+      const int pair = it / nblk, cb = it - pair * nblk;
+      const int g = pair >> 1, h = pair & 1;
+      const int c = cb * 64 + lane;
+      const int ci = (cg0 + g) * 8 + h * 4;   // wave-uniform
+      const int col = c0 + c;
+      const int nval = a.w.cin - ci;          // real channels among the 4 (padding channels read as zero)
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < wx) {
+        if (col >= 0 && col < a.lin) {
+          const float* xp = xb + (int64_t)ci * a.lin + col;
+          if (nval >= 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = xp[(int64_t)e * a.lin];
+            if (do_snake) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = snake_f(v[e], a.snake_alpha[ci + e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < nval) {
+                const float t = xp[(int64_t)e * a.lin];
+                v[e] = do_snake ? snake_f(t, a.snake_alpha[ci + e]) : t;
+              }
           }
-          Xs[r * wx + c] = v;
         }
+        *reinterpret_cast<f32x4*>(Xs + ((g * wx + c) << 3) + (((h ^ (c >> 3)) & 1) << 2)) = v;
       }
     }
     __syncthreads();  // also drains the LDS-DMA (vmcnt(0) is part of the barrier's fence)
-    // ---- multiply: reduction index = (tap, channel pair)
-    for (int tp = 0; tp < (a.dbg == 2 ? 0 : taps); ++tp) {
+    // ---- multiply
+    for (int tp = 0; tp < taps; ++tp) {
       const int xoff = tap_off0 + tp * a.tap_step;
 #pragma unroll
-      for (int k2 = 0; k2 < CI / 2; ++k2) {
-        const int row = k2 * 2 + lk;
-        float af[MT], bf[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = Ws[(tp * CI + row) * CO_T + i * 32 + li];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = Xs[row * wx + (qw + j * 32 + li) * a.x_stride + xoff];
+      for (int g = 0; g < G; ++g) {
+        f32x4 af[MT], bf[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
+          af[i] = *reinterpret_cast<const f32x4*>(a_lane + ((tp * G + g) * CO_T + i * 32) * 32);
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) {
+          const int c = (qw + j * 32 + li) * a.x_stride + xoff;
+          bf[j] = *reinterpret_cast<const f32x4*>(Xs + ((g * wx + c) << 3) + (((lk ^ (c >> 3)) & 1) << 2));
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], bf[j][st], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -222,167 +245,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, i
     }
 }
 
-// Pipelined variant: the weight tile is double-buffered in LDS and the DMA of step c+1 is issued right
-// before the MFMAs of step c; the input-tile elements of step c+1 are fetched into (few) registers at the
-// same point and written to LDS (with Snake) after the MFMAs.  Global latency hides behind the matrix
-// pipe inside one work-group instead of relying on other work-groups.
-constexpr int CONV_XR = 16;  // input-tile elements per thread held across the MFMA phase (CI*wx <= 4096)
-
-template <int MT, int NT, int CI>
-__global__ __launch_bounds__(256) void conv_mfma_pipe_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
-  constexpr int ROWB = CO_T * 4;
-  const int taps = a.w.taps;
-  const int nw = taps * CI * CO_T;
-  float* Wbuf[2] = {smem, smem + nw};
-  float* Xs = smem + 2 * nw;
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 31, lk = lane >> 5;
-  const int q0 = blockIdx.x * TT;
-  const int co0 = blockIdx.y * CO_T;
-  const int b = blockIdx.z / a.w.phases, phase = blockIdx.z % a.w.phases;
-  const int c0 = q0 * a.x_stride + a.tap_base - tap_off0;
-  const float* xb = a.x + (int64_t)b * a.w.cin * a.lin;
-  const float* wph = a.w.w + (int64_t)phase * taps * a.w.cin_pad * a.w.cout_pad;
-  const int n_pieces = nw / 256;
-  const bool do_snake = a.snake_alpha != nullptr;
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int qw = wave * NT * 32;
-
-  auto dma_w = [&](int ci0, float* dst) {
-    for (int p = wave; p < n_pieces; p += 4) {
-      const int o = p * 1024 + lane * 16;
-      const int row = o / ROWB, cb = o - row * ROWB;
-      const int tp = row / CI, r = row - tp * CI;
-      const char* g = reinterpret_cast<const char*>(wph + ((int64_t)tp * a.w.cin_pad + ci0 + r) * a.w.cout_pad + co0) + cb;
-      __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(reinterpret_cast<char*>(dst) + p * 1024), 16, 0, 0);
-    }
-  };
-  // element u of this thread: row = wave + 4*(u / XPR), column = lane + 64*(u % XPR), XPR = ceil(wx/64)
-  const int xpr = (wx + 63) >> 6;
-  float xr[CONV_XR];
-  auto load_x = [&](int ci0) {
-#pragma unroll
-    for (int u = 0; u < CONV_XR; ++u) {
-      const int rr = u / xpr, cc = u - rr * xpr;
-      const int r = wave + 4 * rr, c = lane + 64 * cc;
-      const int ci = ci0 + r, col = c0 + c;
-      float v = 0.f;
-      if (r < CI && c < wx && ci < a.w.cin && col >= 0 && col < a.lin) v = xb[(int64_t)ci * a.lin + col];
-      xr[u] = v;
-    }
-  };
-  auto store_x = [&](int ci0) {
-#pragma unroll
-    for (int u = 0; u < CONV_XR; ++u) {
-      const int rr = u / xpr, cc = u - rr * xpr;
-      const int r = wave + 4 * rr, c = lane + 64 * cc;
-      if (r < CI && c < wx) {
-        float v = xr[u];
-        const int ci = ci0 + r;
-        if (do_snake && ci < a.w.cin) v = snake_f(v, a.snake_alpha[ci]);
-        Xs[r * wx + c] = v;
-      }
-    }
-  };
-
-  dma_w(0, Wbuf[0]);
-  load_x(0);
-  int cur = 0;
-  for (int ci0 = 0; ci0 < a.w.cin_pad; ci0 += CI) {
-    store_x(ci0);
-    __syncthreads();  // Xs visible; the DMA of this step has landed (barrier fence waits vmcnt(0))
-    const float* Ws = Wbuf[cur];
-    if (ci0 + CI < a.w.cin_pad) {
-      dma_w(ci0 + CI, Wbuf[cur ^ 1]);
-      load_x(ci0 + CI);
-    }
-    for (int tp = 0; tp < taps; ++tp) {
-      const int xoff = tap_off0 + tp * a.tap_step;
-#pragma unroll
-      for (int k2 = 0; k2 < CI / 2; ++k2) {
-        const int row = k2 * 2 + lk;
-        float af[MT], bf[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = Ws[(tp * CI + row) * CO_T + i * 32 + li];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = Xs[row * wx + (qw + j * 32 + li) * a.x_stride + xoff];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();  // everyone is done reading Xs / Wbuf[cur]
-    cur ^= 1;
-  }
-
-  float* ob = a.out + (int64_t)b * a.w.cout * a.lout;
-  const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : nullptr;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int q = q0 + qw + j * 32 + li;
-      if (q >= ncols) continue;
-      const int col = q * a.out_stride + phase;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (co >= a.w.cout) continue;
-        float v = acc[i][j][r];
-        if (a.w.bias) v += a.w.bias[co];
-        if (a.act == ACT_GELU) v = gelu_f(v);
-        if (a.gamma) v *= a.gamma[co];
-        if (rb) v += rb[(int64_t)co * a.lout + col];
-        ob[(int64_t)co * a.lout + col] = v;
-      }
-    }
-}
-
-template <int MT, int NT, int CI>
+template <int MT, int NT, int G>
 static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
   const ConvW& w = a.w;
   constexpr int TT = 4 * NT * 32, CO_T = MT * 32;
   const int wx = (TT - 1) * a.x_stride + span;
-  const size_t smem = (size_t)(CI * wx + w.taps * CI * CO_T) * sizeof(float);
+  const size_t smem = (size_t)(G * wx * 8 + w.taps * G * CO_T * 8) * sizeof(float);
   FMI_REQUIRE(smem <= 160 * 1024, "conv: LDS tile of %zu bytes exceeds 160 KiB", smem);
-  static const bool allow_dma = []() { const char* e = getenv("FMI_CONV_DMA"); return !(e && e[0] == '0'); }();
-  // the DMA copies whole CO_T-wide rows: every tile must lie inside the padded weight rows
-  const bool dma = allow_dma && (w.cout_pad % CO_T == 0) && (w.cin_pad % CI == 0);
-  dim3 grid(cdiv(ncols, TT), cdiv(w.cout_pad, CO_T), a.B * w.phases), block(256);
-  static const bool allow_pipe = []() { const char* e = getenv("FMI_CONV_PIPE"); return !(e && e[0] == '0'); }();
-  const int xpr = (wx + 63) / 64;
-  const size_t smem_pipe = (size_t)(CI * wx + 2 * w.taps * CI * CO_T) * sizeof(float);
-  if (dma && allow_pipe && a.dbg == 0 && (CI / 4) * xpr <= CONV_XR && CI % 4 == 0 && smem_pipe <= 80 * 1024) {
-    if (smem_pipe > 64 * 1024)
-      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_pipe_kernel<MT, NT, CI>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pipe));
-    hipLaunchKernelGGL((conv_mfma_pipe_kernel<MT, NT, CI>), grid, block, smem_pipe, s, a, ncols, wx, tap_off0);
-    FMI_CHECK_HIP(hipGetLastError());
-    return FMI_OK;
-  }
-  if (dma) {
-    if (smem > 64 * 1024)
-      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, CI, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, CI, true>), grid, block, smem, s, a, ncols, wx, tap_off0);
-  } else {
-    if (smem > 64 * 1024)
-      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, CI, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, CI, false>), grid, block, smem, s, a, ncols, wx, tap_off0);
-  }
+  FMI_REQUIRE(w.cout_pad % CO_T == 0 && (w.cin_pad >> 3) % G == 0, "conv: tile does not divide the packed weight");
+  dim3 grid(cdiv(ncols, TT), w.cout_pad / CO_T, a.B * w.phases), block(256);
+  if (smem > 64 * 1024)
+    FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, G>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, G>), grid, block, smem, s, a, ncols, wx, tap_off0);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -390,26 +265,20 @@ static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, h
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   const ConvW& w = a.w;
   FMI_REQUIRE(w.w && w.cin_pad % 8 == 0 && w.cout_pad % 32 == 0, "conv: weights not packed");
-  {  // profiling switch, re-read per launch (cheap) so that one process can sweep it
-    const char* e = getenv("FMI_CONV_DBG");
-    const_cast<ConvArgs&>(a).dbg = e ? atoi(e) : 0;
-  }
   const int ncols = (a.out_stride == 1) ? a.lout : a.lout / a.out_stride;
   const int tap_off0 = (a.tap_step < 0) ? -(w.taps - 1) * a.tap_step : 0;
   const int span = (w.taps - 1) * (a.tap_step < 0 ? -a.tap_step : a.tap_step) + 1;
   const int ct = w.cout_pad / 32;
   // tile height: the largest of 4/3/2/1 (x32 rows) that divides the channel tiles, so that no
-  // work-group multiplies padding (C = 192 -> 2 x 96, not 128 + 64)
+  // work-group multiplies padding (C = 192 -> 2 x 96, not 128 + 64) and every DMA piece is inside the weight
   int MT = 1;
   for (int m : {4, 3, 2})
     if (ct % m == 0) { MT = m; break; }
-  if (ct >= 8 && MT < 4 && ct % 4 != 0 && ct % 3 != 0) MT = 4;  // large odd counts: accept a ragged last tile
+  // k = 1 layers hold almost no math per 8 channels: stage 32 at a time
   const bool k1 = (w.taps == 1 && a.x_stride == 1 && w.cin_pad % 32 == 0);
 #define FMI_CONV(MT_, NT_)                                                            \
-  return k1 ? launch_conv_t<MT_, NT_, 32>(a, ncols, tap_off0, span, s)                \
-            : launch_conv_t<MT_, NT_, 8>(a, ncols, tap_off0, span, s)
-  static const bool wide = []() { const char* e = getenv("FMI_CONV_WIDE"); return e && e[0] == '1'; }();  // measured slower
-  if (MT == 4 && wide && ncols >= 2048) FMI_CONV(4, 2);  // 256-column tiles: each staged weight tile feeds 2x the MFMAs
+  return k1 ? launch_conv_t<MT_, NT_, 4>(a, ncols, tap_off0, span, s)                 \
+            : launch_conv_t<MT_, NT_, 1>(a, ncols, tap_off0, span, s)
   if (MT == 4) FMI_CONV(4, 1);
   if (MT == 3) FMI_CONV(3, 2);
   if (MT == 2) FMI_CONV(2, 2);
