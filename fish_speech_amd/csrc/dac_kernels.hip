@@ -120,7 +120,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // instructions per MFMA) was bound by the SIMD's instruction issue, not by the matrix pipe or the LDS
 // (profiles/r01_pmc_conv.txt).  Reduction step s of a group pairs channels (s, 4+s): lane half 0 / 1.
 template <int MT, int NT, int G>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
+__global__ __launch_bounds__(256, (MT == 4 && NT == 1) ? 4 : (MT * NT <= 4 ? 3 : 2)) void conv_mfma_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
   const int taps = a.w.taps;
@@ -221,26 +221,50 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int ncols, i
     __syncthreads();
   }
 
-  // ---- epilogue: out = res + gamma * act(acc + bias); lanes run along time (coalesced)
+  // ---- epilogue: out = res + gamma * act(acc + bias); lanes run along time (coalesced).  A branchy version
+  // (per-element tests of bias / gamma / res / row bound) cost 2-3 serialized memory round trips per output
+  // element and dominated the k = 1 layers: bias and gamma of the tile's rows go through LDS (the operand
+  // tiles are dead after the last barrier), residual loads use clamped always-valid 32-bit offsets and are
+  // issued 16 at a time.
+  float* sb = smem;          // [CO_T] bias (0 when absent), then [CO_T] gamma (1 when absent)
+  float* sg = smem + CO_T;
+  const int co_last = a.w.cout - 1;
+  if (tid < CO_T) {
+    const int co = min(co0 + tid, co_last);
+    sb[tid] = a.w.bias ? a.w.bias[co] : 0.f;
+    sg[tid] = a.gamma ? a.gamma[co] : 1.f;
+  }
+  __syncthreads();
   float* ob = a.out + (int64_t)b * a.w.cout * a.lout;
-  const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : nullptr;
+  const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : ob;  // same layout as out
+  const bool has_res = a.res != nullptr;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int q = q0 + qw + j * 32 + li;
-      if (q >= ncols) continue;
-      const int col = q * a.out_stride + phase;
+      const bool live = q < ncols;
+      const int col = (live ? q : 0) * a.out_stride + phase;
+      const int row0 = i * 32 + 4 * lk;   // tile row of r = 0; r -> row0 + 8*(r>>2) + (r&3)
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (co >= a.w.cout) continue;
-        float v = acc[i][j][r];
-        if (a.w.bias) v += a.w.bias[co];
-        if (a.act == ACT_GELU) v = gelu_f(v);
-        if (a.gamma) v *= a.gamma[co];
-        if (rb) v += rb[(int64_t)co * a.lout + col];
-        ob[(int64_t)co * a.lout + col] = v;
+        const int co = min(co0 + row0 + 8 * (r >> 2) + (r & 3), co_last);
+        rv[r] = has_res ? rb[co * a.lout + col] : 0.f;
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb + row0 + 8 * r4);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg + row0 + 8 * r4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = r4 * 4 + e;
+          float v = acc[i][j][r] + b4[e];
+          if (a.act == ACT_GELU) v = gelu_f(v);
+          v = v * g4[e] + rv[r];
+          const int co = co0 + row0 + 8 * r4 + e;
+          if (live && co <= co_last) ob[co * a.lout + col] = v;
+        }
       }
     }
 }
