@@ -107,6 +107,7 @@ int main() {
     printf("%s  (%.1f MB, M=%d)\n", sh.name, bytes / 1e6, M);
     BU(16, 5, 1); BU(16, 5, 2); BU(16, 5, 4); BU(8, 10, 1); BU(8, 10, 2); BU(10, 8, 2); BU(10, 8, 1); BU(16, 8, 1); BU(16, 8, 2); BU(8, 16, 1); BU(16, 19, 1); BU(8, 38, 1); BU(4, 20, 1); BU(4, 20, 2);
     V(8, 2, 2, true); V(16, 2, 2, true); V(16, 2, 1, true); V(8, 4, 1, true);
+    if (getenv("TILES4")) { V(8, 2, 4, true); V(8, 1, 4, true); V(16, 1, 4, true); V(16, 2, 4, true); V(4, 2, 4, true); V(8, 4, 4, true); V(8, 1, 2, true); V(8, 3, 2, true); }
     if (getenv("FULL_SWEEP")) {
     V(4, 4, 1, true); V(4, 4, 2, true); V(4, 4, 4, true); V(4, 8, 1, true); V(4, 8, 2, true); V(4, 2, 2, true); V(4, 4, 2, false);
     V(2, 4, 2, true); V(2, 8, 2, true); V(2, 4, 4, true); V(1, 4, 4, true); V(1, 8, 4, true); V(1, 8, 2, true);
