@@ -139,3 +139,49 @@ def test_stream_equals_offline_codes_and_audio(tiny_model, small_codec, ignore_e
     if ignore_eos:
         assert lengths == [n_new - 1] * 3
     model.set_ignore_eos(False)
+
+
+def test_generate_long_end_to_end_on_the_gpu():
+    """Text -> prompt builder -> real Dual-AR kernels -> codes, two text chunks with context carry
+    (SURVEY.md row a15).  Each chunk's codes must equal a direct `generate` on the prompt generate_long built
+    (same seed), and the second prompt must contain the first chunk's codes as VQ columns."""
+    from fish_speech_amd import text2semantic as T2S
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR, generate
+    from oracle import dual_ar as O
+    from oracle.fake_tokenizer import ByteTokenizer
+
+    tok = ByteTokenizer()
+    cfg = O.DualARConfig(vocab_size=tok.vocab_size + 4, dim=128, n_layer=2, n_head=4, n_local_heads=2, head_dim=32,
+                         intermediate_size=256, max_seq_len=2048 + 512, codebook_size=4096, num_codebooks=10,
+                         semantic_begin_id=tok.semantic_begin_id, semantic_end_id=tok.semantic_end_id,
+                         im_end_id=tok.get_token_id("<|im_end|>"), n_fast_layer=2)
+    state = O.make_synthetic_state(cfg, seed=5, head_gain=4.0)
+    model = MiDualAR.from_state_dict(DualARConfig.from_any(cfg), state, device=DEV, im_end_id=cfg.im_end_id)
+    model.tokenizer = tok
+    model.setup_caches(1, cfg.max_seq_len)
+    prompts = []
+
+    def recording_generate(**kw):
+        prompts.append(kw["prompt"].cpu().clone())
+        kw.pop("decode_one_token", None), kw.pop("audio_masks", None), kw.pop("audio_parts", None)
+        return generate(seed=1234 + len(prompts), **kw)
+
+    T2S.generate = recording_generate
+    try:
+        text = "<|speaker:0|>First chunk of text.<|speaker:1|>Second chunk, another speaker."
+        out = list(T2S.generate_long(model=model, device=DEV, text=text, max_new_tokens=12, chunk_length=30,
+                                     temperature=0.8, top_p=0.8, top_k=20))
+    finally:
+        T2S.generate = T2S._default_generate
+    assert [r.action for r in out] == ["sample", "sample", "next"] and len(prompts) == 2
+    for i, r in enumerate(out[:2]):
+        assert r.codes.shape[0] == 10 and 1 <= r.codes.shape[1] <= 11
+        assert int(r.codes.min()) >= 0 and int(r.codes.max()) < 4096
+        y = generate(model=model, prompt=prompts[i].to(DEV), max_new_tokens=12, seed=1235 + i, temperature=0.8,
+                     top_p=0.8, top_k=20)
+        assert torch.equal(y[1:, prompts[i].shape[1]:-1].cpu(), r.codes.cpu())
+    n0 = out[0].codes.shape[1]
+    p1 = prompts[1]
+    vq = (p1[0] >= tok.semantic_begin_id) & (p1[0] <= tok.semantic_end_id)
+    assert int(vq.sum()) == n0 and torch.equal(p1[1:, vq], out[0].codes.cpu())
+    assert torch.equal(p1[:, : prompts[0].shape[1]], prompts[0])          # the first prompt is a prefix of the second
