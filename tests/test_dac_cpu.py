@@ -104,3 +104,35 @@ def test_stream_chunk_schedule():
     import pytest
     with pytest.raises(ValueError):
         chunk_schedule(10, 0, 4)
+
+
+def test_extract_vq_sharding_and_cli_surface(tmp_path, monkeypatch):
+    """Host logic of the batch encode tool (tools/vqgan/extract_vq.py:143-207): rank slicing r::R over the files
+    that have no .npy yet, rank/world discovery, the reference's options."""
+    from click.testing import CliRunner
+
+    from fish_speech_amd import extract_vq as X
+
+    for i in range(7):
+        (tmp_path / f"f{i}.wav").write_bytes(b"x")
+    (tmp_path / "notes.txt").write_text("not audio")
+    (tmp_path / "f3.npy").write_bytes(b"x")
+    files = X.list_audio_files(str(tmp_path))
+    assert [f.name for f in files] == [f"f{i}.wav" for i in range(7)]
+    parts = [X.pending_for_rank(files, r, 3) for r in range(3)]
+    assert sorted(sum(parts, [])) == sorted(f for f in files if f.name != "f3.wav")
+    assert [f.name for f in parts[0]] == ["f0.wav", "f4.wav"]           # files[rank::world] after the skip
+    fl = tmp_path / "list.txt"
+    fl.write_text(f"{tmp_path / 'f1.wav'}|spk|en|hello\n\n{tmp_path / 'f2.wav'}|spk|en|x\n")
+    assert [p.name for p in X.load_filelist(fl)] == ["f1.wav", "f2.wav"]
+    for k in ("SLURM_PROCID", "SLURM_NTASKS", "RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert X._rank_world() == (0, 1)
+    monkeypatch.setenv("RANK", "2"), monkeypatch.setenv("WORLD_SIZE", "4")
+    assert X._rank_world() == (2, 4)
+    monkeypatch.setenv("SLURM_PROCID", "1"), monkeypatch.setenv("SLURM_NTASKS", "8")
+    assert X._rank_world() == (1, 8)
+    res = CliRunner().invoke(X.main, ["--help"])
+    assert res.exit_code == 0
+    for flag in ("--num-workers", "--config-name", "--checkpoint-path", "--batch-size", "--filelist", "FOLDER"):
+        assert flag in res.output

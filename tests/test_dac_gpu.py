@@ -160,3 +160,43 @@ def test_codec_edge_cases_and_misuse(small):
     a = codec.from_indices(idx32.to(DEV))
     b = codec.from_indices(idx32.to(torch.int64).to(DEV))
     assert torch.equal(a, b)
+
+
+def test_extract_vq_batch_tool(small, tmp_path):
+    """tools/vqgan/extract_vq.py's job on the GPU codec: a ragged batch of files (one stereo, one unreadable, one
+    already done) -> per-file .npy equal to encoding each file alone, and to the oracle's codes."""
+    from scipy.io import wavfile
+
+    from fish_speech_amd import extract_vq as X
+
+    cfg, state, z, codec = small
+    g = torch.Generator().manual_seed(3)
+    sr = cfg.sample_rate
+    clips = {}
+    for i, n in enumerate([cfg.frame_length * 3 + 17, cfg.frame_length * 5, cfg.frame_length - 5]):
+        t = torch.arange(n) / sr
+        x = (0.3 * torch.sin(2 * np.pi * (200 + 90 * i) * t) + 0.05 * torch.randn(n, generator=g)).numpy().astype(np.float32)
+        clips[f"sub/clip{i}.wav"] = x
+    (tmp_path / "sub").mkdir()
+    for name, x in clips.items():
+        wavfile.write(str(tmp_path / name), sr, np.stack([x, x], axis=1) if name.endswith("1.wav") else x)
+    (tmp_path / "broken.wav").write_bytes(b"not a wav file")
+    wavfile.write(str(tmp_path / "done.wav"), sr, clips["sub/clip0.wav"])
+    np.save(tmp_path / "done.npy", np.zeros((1, 1)))
+    files = X.list_audio_files(str(tmp_path))
+    assert len(files) == 5
+    mine = X.pending_for_rank(files, 0, 1)
+    assert len(mine) == 4 and not any(f.name == "done.wav" for f in mine)
+    assert sorted(X.pending_for_rank(files, 0, 2) + X.pending_for_rank(files, 1, 2)) == sorted(mine)
+    seconds = X.process_batch(mine, codec)
+    assert abs(seconds - sum(len(x) for x in clips.values()) / sr) < 1e-6
+    assert not (tmp_path / "broken.npy").exists() and np.load(tmp_path / "done.npy").shape == (1, 1)
+    orc = D.DacOracle(cfg, state)
+    for name, x in clips.items():
+        got = np.load((tmp_path / name).with_suffix(".npy"))
+        audio = torch.from_numpy(x).view(1, 1, -1)
+        want, lens = orc.encode(audio, torch.tensor([audio.shape[-1]]))
+        assert got.dtype == np.int64 and got.shape == (cfg.n_codebooks + 1, int(lens[0]))
+        alone, _ = codec.encode(audio.to(DEV), torch.tensor([audio.shape[-1]], device=DEV))
+        assert np.array_equal(got, alone[0].cpu().numpy()), name      # batch == single file
+        assert np.array_equal(got, want[0, :, : int(lens[0])].numpy()), name
