@@ -770,11 +770,11 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
   __shared__ float s_k[D], s_v[D];
   __shared__ float s_m[NW][G], s_l[NW][G];
   __shared__ float s_acc[NW][G][D];
-  const int r = blockIdx.x, kvh = blockIdx.y;
+  const int r = blockIdx.x, kvh = blockIdx.y, gz = blockIdx.z;  // gz: which G of this kv head's Gt query heads
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = a.row_slot[r];
   const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
-  const int H = a.H, KVH = a.KVH;
+  const int H = a.H, KVH = a.KVH, Gt = H / KVH;
   const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
   const bf16_t* src = a.qkv + (int64_t)r * (H + 2 * KVH) * D;
 
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
 
   // ---- phase 1
   for (int item = wave; item < G + 2; item += NW) {
-    const int h = item == 0 ? H + kvh : (item == 1 ? H + KVH + kvh : kvh * G + (item - 2));
+    const int h = item == 0 ? H + kvh : (item == 1 ? H + KVH + kvh : kvh * Gt + gz * G + (item - 2));
     const bool act = lane < D / 2;
     const int p = act ? lane : 0;
     uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
@@ -825,10 +825,12 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
         s_q[item - 2][2 * p] = bf2f(o0);
         s_q[item - 2][2 * p + 1] = bf2f(o1);
       } else {
-        const int page = bt[pos / KV_PAGE];
-        bf16_t* pool = (item == 0) ? a.kpool : a.vpool;
-        *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kvh) * KV_PAGE + pos % KV_PAGE) * D + 2 * p) =
-            (uint32_t)o0 | ((uint32_t)o1 << 16);
+        if (gz == 0) {  // every split recomputes the new k/v row for its LDS copy; one of them appends it
+          const int page = bt[pos / KV_PAGE];
+          bf16_t* pool = (item == 0) ? a.kpool : a.vpool;
+          *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kvh) * KV_PAGE + pos % KV_PAGE) * D + 2 * p) =
+              (uint32_t)o0 | ((uint32_t)o1 << 16);
+        }
         float* dst = (item == 0) ? s_k : s_v;
         dst[2 * p] = bf2f(o0);
         dst[2 * p + 1] = bf2f(o1);
@@ -943,19 +945,26 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
       L += s_l[w][gq] * wgt;
       O += s_acc[w][gq][d] * wgt;
     }
-    a.out[((int64_t)r * H + kvh * G + gq) * D + d] = f2bf(O / L);
+    a.out[((int64_t)r * H + kvh * Gt + gz * G + gq) * D + d] = f2bf(O / L);
   }
 }
 
+// The query heads of a kv head are split over `split` work-groups (each re-reads the K/V rows, which are L2
+// hits): rows x KVH work-groups alone (64 at batch 8) leave three quarters of the CUs idle, and the per-head
+// score/softmax/PV arithmetic is the serial part of this latency-bound kernel.  FMI_ATTN_SPLIT overrides.
 template <int D>
 static int launch_attn_decode_d(const AttnArgs& a, hipStream_t s) {
-  const int G = a.H / a.KVH;
-  dim3 grid(a.rows, a.KVH), block(512);
+  const int Gt = a.H / a.KVH;
+  static const int env_split = []() { const char* e = getenv("FMI_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+  int split = env_split > 0 ? env_split : Gt;   // measured at batch 8, S2 shape: frame 5.31 / 5.18 / 5.07 ms for 1 / 2 / 4
+  if (Gt % split != 0) split = 1;
+  const int G = Gt / split;
+  dim3 grid(a.rows, a.KVH, split), block(512);
   switch (G) {
     case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 1>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 2>), grid, block, 0, s, a); break;
     case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 4>), grid, block, 0, s, a); break;
-    default: return set_error(FMI_EINVAL, "attn: GQA ratio %d unsupported", G);
+    default: return set_error(FMI_EINVAL, "attn: GQA ratio %d unsupported", Gt);
   }
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
