@@ -86,15 +86,28 @@ class DualARConfig:
     @classmethod
     def from_fish_qwen3_omni(cls, data: dict, im_end_id: int, semantic_begin_id: Optional[int] = None,
                              semantic_end_id: Optional[int] = None) -> "DualARConfig":
-        """config.json of model_type 'fish_qwen3_omni' (llama.py:90-143)."""
+        """config.json of model_type 'fish_qwen3_omni' (llama.py:99-143), with the reference's fallbacks for
+        absent keys (dataclass defaults and __post_init__, llama.py:27-72,165-193): head_dim 64, n_local_heads =
+        n_head, intermediate_size = 8*dim/3 rounded up to 256, rope_base 1e4, norm_eps 1e-5, max_seq_len 2048.
+        Options the MI355X path does not implement are refused instead of ignored."""
         tc, adc = data["text_config"], data["audio_decoder_config"]
+        for blk, name in ((tc, "text_config"), (adc, "audio_decoder_config")):
+            for opt in ("attention_qkv_bias", "attention_o_bias"):
+                if blk.get(opt):
+                    raise ValueError(f"{name}.{opt}=true is not supported by fish_speech_amd")
+        if not tc.get("tie_word_embeddings", True):
+            raise ValueError("text_config.tie_word_embeddings=false is not supported by fish_speech_amd")
+        dim = tc["dim"]
+        inter = tc.get("intermediate_size")
+        if inter is None:
+            inter = -(-int(2 * 4 * dim / 3) // 256) * 256      # find_multiple(n_hidden, 256), llama.py:67-70
+        n_local = tc.get("n_local_heads", -1)
         return cls(
             vocab_size=tc["vocab_size"], n_layer=tc["n_layer"], n_head=tc["n_head"],
-            n_local_heads=tc.get("n_local_heads", -1) if tc.get("n_local_heads", -1) != -1 else tc["n_head"],
-            head_dim=tc.get("head_dim") or tc["dim"] // tc["n_head"], dim=tc["dim"],
-            intermediate_size=tc["intermediate_size"], rope_base=tc.get("rope_base", 10000),
-            norm_eps=tc.get("norm_eps", 1e-5), max_seq_len=tc.get("max_seq_len", 2048),
-            attention_qk_norm=tc.get("attention_qk_norm", False),
+            n_local_heads=tc["n_head"] if n_local in (-1, None) else n_local,
+            head_dim=tc.get("head_dim") or 64, dim=dim, intermediate_size=inter,
+            rope_base=tc.get("rope_base", 10000), norm_eps=tc.get("norm_eps", 1e-5),
+            max_seq_len=tc.get("max_seq_len", 2048), attention_qk_norm=tc.get("attention_qk_norm", False),
             semantic_begin_id=semantic_begin_id if semantic_begin_id is not None else data.get("semantic_start_token_id", 0),
             semantic_end_id=semantic_end_id if semantic_end_id is not None else data.get("semantic_end_token_id", 0),
             im_end_id=im_end_id, scale_codebook_embeddings=True, norm_fastlayer_input=True,

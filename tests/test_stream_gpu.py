@@ -185,3 +185,75 @@ def test_generate_long_end_to_end_on_the_gpu():
     vq = (p1[0] >= tok.semantic_begin_id) & (p1[0] <= tok.semantic_end_id)
     assert int(vq.sum()) == n0 and torch.equal(p1[1:, vq], out[0].codes.cpu())
     assert torch.equal(p1[:, : prompts[0].shape[1]], prompts[0])          # the first prompt is a prefix of the second
+
+
+def test_from_pretrained_reads_an_s2_style_checkpoint_directory(tmp_path, monkeypatch):
+    """SURVEY.md row a17 end to end: config.json of model_type fish_qwen3_omni, sharded safetensors with the HF
+    tensor names (text_model.model.* / audio_decoder.*) and separate wq/wk/wv (Attention.load_hook,
+    llama.py:877-882), ids injected from the tokenizer -> the loaded model generates exactly what a model built
+    straight from the state dict generates."""
+    import json
+    import sys
+    import types
+
+    from safetensors.torch import save_file
+
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR, generate
+    from oracle import dual_ar as O
+    from oracle.fake_tokenizer import ByteTokenizer
+
+    tok = ByteTokenizer()
+    cfg = O.DualARConfig(vocab_size=tok.vocab_size + 4, dim=128, n_layer=2, n_head=4, n_local_heads=2, head_dim=32,
+                         intermediate_size=256, max_seq_len=256, codebook_size=4096, num_codebooks=10,
+                         semantic_begin_id=tok.semantic_begin_id, semantic_end_id=tok.semantic_end_id,
+                         im_end_id=tok.get_token_id("<|im_end|>"), n_fast_layer=2, rope_base=1000000.0, norm_eps=1e-6)
+    state = O.make_synthetic_state(cfg, seed=21, head_gain=4.0)
+    hf = {}
+    for k, v in state.items():
+        if k.startswith("fast_"):
+            name = "audio_decoder." + k[len("fast_"):]
+        elif k.startswith("codebook_embeddings."):
+            name = "audio_decoder." + k
+        else:
+            name = "text_model.model." + k
+        if name.endswith("attention.wqkv.weight") and ".layers.0." in name and name.startswith("text_model"):
+            q = cfg.n_head * cfg.head_dim
+            kv = cfg.n_local_heads * cfg.head_dim
+            pre = name[: -len("wqkv.weight")]
+            hf[pre + "wq.weight"], hf[pre + "wk.weight"], hf[pre + "wv.weight"] = (
+                v[:q].contiguous(), v[q:q + kv].contiguous(), v[q + kv:].contiguous())
+        else:
+            hf[name] = v.contiguous()
+    names = sorted(hf)
+    shards = {"model-00001-of-00002.safetensors": names[: len(names) // 2],
+              "model-00002-of-00002.safetensors": names[len(names) // 2:]}
+    for fn, ks in shards.items():
+        save_file({k: hf[k] for k in ks}, str(tmp_path / fn))
+    (tmp_path / "model.safetensors.index.json").write_text(json.dumps(
+        {"weight_map": {k: fn for fn, ks in shards.items() for k in ks}}))
+    (tmp_path / "config.json").write_text(json.dumps({
+        "model_type": "fish_qwen3_omni", "semantic_start_token_id": 0, "semantic_end_token_id": 0,
+        "text_config": {"vocab_size": cfg.vocab_size, "n_layer": 2, "n_head": 4, "n_local_heads": 2, "head_dim": 32,
+                        "dim": 128, "intermediate_size": 256, "rope_base": 1000000, "norm_eps": 1e-6,
+                        "max_seq_len": 256, "attention_qk_norm": True},
+        "audio_decoder_config": {"vocab_size": 4096, "num_codebooks": 10, "n_layer": 2}}))
+
+    class FishTokenizer:                       # stands in for fish_speech.tokenizer.FishTokenizer (no tokenizer files here)
+        @classmethod
+        def from_pretrained(cls, path):
+            assert str(path) == str(tmp_path)
+            return tok
+
+    pkg, mod = types.ModuleType("fish_speech"), types.ModuleType("fish_speech.tokenizer")
+    mod.FishTokenizer = FishTokenizer
+    pkg.tokenizer = mod
+    monkeypatch.setitem(sys.modules, "fish_speech", pkg)
+    monkeypatch.setitem(sys.modules, "fish_speech.tokenizer", mod)
+
+    loaded = MiDualAR.from_pretrained(str(tmp_path), device=DEV)
+    assert loaded.tokenizer is tok and loaded.config.semantic_begin_id == tok.semantic_begin_id
+    assert loaded.config.im_end_id == cfg.im_end_id and loaded.config.fast_attention_qk_norm is True
+    direct = MiDualAR.from_state_dict(DualARConfig.from_any(cfg), state, device=DEV, im_end_id=cfg.im_end_id)
+    prompt = _prompts(cfg, 1, seed=3)[0]
+    kw = dict(max_new_tokens=10, temperature=0.8, top_p=0.8, top_k=20, seed=99)
+    assert torch.equal(generate(model=loaded, prompt=prompt, **kw), generate(model=direct, prompt=prompt, **kw))
