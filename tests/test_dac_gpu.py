@@ -200,3 +200,24 @@ def test_extract_vq_batch_tool(small, tmp_path):
         alone, _ = codec.encode(audio.to(DEV), torch.tensor([audio.shape[-1]], device=DEV))
         assert np.array_equal(got, alone[0].cpu().numpy()), name      # batch == single file
         assert np.array_equal(got, want[0, :, : int(lens[0])].numpy()), name
+
+
+def test_codec_checkpoint_wrapping_and_engine_call_sites(small):
+    """codec.pth as the training run saves it -- {"state_dict": {"generator.*": ..., "discriminator.*": ...}}
+    (dac/inference.py:29-42) -- loads to the same codec; and the two expressions the inference engine evaluates
+    on the codec object (vq_manager.py:20,44) work verbatim on MiDAC."""
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg, state, z, codec = small
+    wrapped = {"state_dict": {**{"generator." + k: v for k, v in state.items()},
+                              "discriminator.layers.0.weight": torch.zeros(3, 3)}}
+    other = MiDAC(DacConfig.from_any(cfg), device=DEV).load_state_dict(wrapped)
+    codes = torch.from_numpy(z["codes"]).to(DEV)[0]                          # (1+n, T) as the engine holds them
+    a = codec.from_indices(codes[None].clone())[0].squeeze()                 # vq_manager.py:20
+    b = other.from_indices(codes[None].clone())[0].squeeze()
+    assert a.dim() == 1 and torch.equal(a, b)
+    audios = torch.from_numpy(z["audio"]).to(other.device)
+    audio_lengths = torch.tensor([audios.shape[2]], device=other.device, dtype=torch.long)
+    prompt_tokens = other.encode(audios, audio_lengths)[0][0]                # vq_manager.py:44
+    assert prompt_tokens.shape == (cfg.n_codebooks + 1, int(z["lens"][0])) and other.sample_rate == cfg.sample_rate
+    assert np.array_equal(prompt_tokens.cpu().numpy(), z["codes"][0])
