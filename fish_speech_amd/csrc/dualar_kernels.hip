@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __syncthreads();
 
   const int32_t* ids = a.ids;
-  int row = sampler_draw(sh, k, temperature, top_p, seed, (uint32_t)slot, (uint32_t)frame, (uint32_t)draw0, ids, tid);
+  int row = sampler_draw(sh, k, temperature, top_p, seed, 0u /* stream: an utterance's draws depend on its seed only, not on the slot it occupies */, (uint32_t)frame, (uint32_t)draw0, ids, tid);
   int tok = (row < 0) ? 0 : (ids ? ids[row] : row);
 
   if (a.mode == 1) {  // fast codebook draw
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     // second draw at RAS_HIGH_TEMP / RAS_HIGH_TOP_P (inference.py:126-131); always consumed
     const bool second = (a.mode == 0) || (a.prev != nullptr);
     if (second) {
-      int row_h = sampler_draw(sh, k, 1.0f, rbf(0.9f), seed, (uint32_t)slot, (uint32_t)frame, (uint32_t)draw0 + 1, ids, tid);
+      int row_h = sampler_draw(sh, k, 1.0f, rbf(0.9f), seed, 0u /* stream: an utterance's draws depend on its seed only, not on the slot it occupies */, (uint32_t)frame, (uint32_t)draw0 + 1, ids, tid);
       int tok_h = (row_h < 0) ? 0 : (ids ? ids[row_h] : row_h);
       if (use_ras) {
         const int32_t* win = (a.mode == 2) ? a.prev + (int64_t)b * RAS_WIN
@@ -1702,14 +1702,14 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   }
 
   if (a.dbg_stop == 6) return;
-  int tok = small_draw(v, cum, vid, lane, k, temperature, top_p, seed, (uint32_t)slot, (uint32_t)frame, (uint32_t)draw0);
+  int tok = small_draw(v, cum, vid, lane, k, temperature, top_p, seed, 0u /* stream: an utterance's draws depend on its seed only, not on the slot it occupies */, (uint32_t)frame, (uint32_t)draw0);
   if (a.dbg_stop == 7) return;
   if (a.mode == 1) {
     if (lane == 0) a.st.cur[(int64_t)slot * a.st.ncb1 + 1 + a.cb] = tok;
   } else {
     const bool second = (a.mode == 0) || (a.prev != nullptr);
     if (second) {
-      const int tok_h = small_draw(v, cum, vid, lane, k, 1.0f, rbf(0.9f), seed, (uint32_t)slot, (uint32_t)frame,
+      const int tok_h = small_draw(v, cum, vid, lane, k, 1.0f, rbf(0.9f), seed, 0u /* stream: an utterance's draws depend on its seed only, not on the slot it occupies */, (uint32_t)frame,
                                    (uint32_t)draw0 + 1);
       if (use_ras) {
         const int32_t* win = (a.mode == 2) ? a.prev + (int64_t)b * RAS_WIN

@@ -68,3 +68,22 @@ def test_two_process_broadcast_and_gather():
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] and r[2] for r in res), res
+
+
+def test_lpt_partition_of_mixed_length_utterances():
+    """Config 4 (64 mixed-length utterances over 8 GPUs): greedy longest-first packing keeps the heaviest rank
+    within one utterance of the mean; every utterance lands on exactly one rank."""
+    import random
+
+    from fish_speech_amd.scheduler import lpt_order, partition_for_ranks
+
+    rng = random.Random(4)
+    costs = [rng.randint(100, 430) for _ in range(64)]
+    bins = partition_for_ranks(costs, 8)
+    assert sorted(i for b in bins for i in b) == list(range(64))
+    loads = [sum(costs[i] for i in b) for b in bins]
+    assert max(loads) - sum(loads) / 8 <= max(costs)
+    assert max(loads) <= 1.06 * sum(loads) / 8
+    order = lpt_order(costs)
+    assert [costs[i] for i in order] == sorted(costs, reverse=True)
+    assert partition_for_ranks([5.0], 4) == [[0], [], [], []]

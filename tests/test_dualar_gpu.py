@@ -120,7 +120,7 @@ def test_sampler_bit_exact_vs_oracle(lib, top_k, n):
         logits = (torch.randn(B, n, generator=g) * gain).bfloat16()  # many exact bf16 ties
         got = _sample(lib, logits, ids, (0.7, 0.7, top_k, 77, 0), 5, 3, None, (0, 0))
         for b in range(B):
-            want = _oracle_draw(logits[b], ids, vocab, 0.7, 0.7, top_k, 77, b, 5, 3)
+            want = _oracle_draw(logits[b], ids, vocab, 0.7, 0.7, top_k, 77, 0, 5, 3)   # stream keyed by seed only
             assert int(got[b]) == want, (b, int(got[b]), want)
 
 
@@ -145,8 +145,8 @@ def test_sampler_ras_selection(lib):
     sem = (120, 350)
     got = _sample(lib, logits, ids, (0.7, 0.7, 30, 5, 1), 2, 0, prev, sem)
     for b in range(B):
-        tn = _oracle_draw(logits[b], ids, 500, 0.7, 0.7, 30, 5, b, 2, 0)
-        th = _oracle_draw(logits[b], ids, 500, 1.0, 0.9, 30, 5, b, 2, 1)
+        tn = _oracle_draw(logits[b], ids, 500, 0.7, 0.7, 30, 5, 0, 2, 0)
+        th = _oracle_draw(logits[b], ids, 500, 1.0, 0.9, 30, 5, 0, 2, 1)
         want = th if (sem[0] <= tn <= sem[1]) else tn
         assert int(base[b]) == tn and int(got[b]) == want
 
@@ -245,7 +245,7 @@ def test_batch_equals_single_utterance_and_graph_equals_eager():
                            seeds=seeds)
     model.set_graph(False)
     for i, p in enumerate(prompts):
-        # slot index feeds the uniform stream id: run each utterance alone in ITS slot via seeds only
+        # the uniform stream is keyed by the seed only: run each utterance alone with its seed
         single = generate_batch(model=model, prompts=[prompts[0]] * i + [p], max_new_tokens=12, temperature=0.7,
                                 top_p=0.7, top_k=30, seeds=seeds[: i + 1])[-1]
         assert torch.equal(single, batch[i]), i
@@ -319,7 +319,7 @@ def test_s2_shape_ragged_batch_equals_single_and_graph_equals_eager(s2_model):
         tok = gen[0]
         ok = ((tok >= cfg.semantic_begin_id) & (tok <= cfg.semantic_end_id)) | (tok == cfg.im_end_id) | (tok == 0)
         assert bool(ok.all()), "slow token outside the constrained set (semantic ids, <|im_end|>, or the u==0 token 0)"
-    for i in (2, 5):  # batch-1 runs in the same slot (slot = uniform stream id)
+    for i in (2, 5):  # batch-1 runs (the slot does not matter: the uniform stream is keyed by the seed)
         single = generate_batch(model=model, prompts=[prompts[0]] * i + [prompts[i]], seeds=seeds[: i + 1], **kw)[-1]
         assert torch.equal(single, batch[i]), f"batch result of utterance {i} differs from its batch-1 run"
 
