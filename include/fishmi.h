@@ -77,7 +77,7 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len);
 typedef struct fmi_sampling {
   float temperature, top_p; /* rounded to bf16 inside, like inference.py:305-306 */
   int32_t top_k;
-  uint32_t seed;    /* counter-based uniform generator, stream = slot */
+  uint32_t seed;    /* counter-based uniform generator keyed by (seed, frame, draw, vocab id): slot-independent */
   int32_t use_ras;  /* 1 = repetition-aware sampling of inference.py:118-144 */
 } fmi_sampling;
 
