@@ -28,7 +28,9 @@ struct SlotState {
   int max_pages, max_frames, ncb1;
 };
 
-// Weight tile packing: row-major (N,K) bf16 -> [N/16][K/32][64 lanes][8] MFMA fragments.
+// Weight tile packing: row-major (N,K) bf16 -> [N/16][K/32][64 lanes][8] MFMA fragments; inside every pair of
+// k-tiles the 8-element chunks are permuted (packed_k0 in dualar_kernels.hip) so that one all-lanes activation load
+// serves both tiles.
 // interleave: 0 identity; 1/2 = w1/w3 halves of the SwiGLU pair, 16-row blocks alternating.
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int interleave, hipStream_t s);
 // gather `n` rows listed in ids_dev (int32 vocab ids, on device) then pack (live LM-head rows).

@@ -22,10 +22,31 @@ namespace fmi {
 // weight packing
 // =====================================================================================
 
+// Packed layout [N/16][K/32][64 lanes][8]: one 1 KiB tile = one v_mfma_f32_16x16x32_bf16 A operand, lane = kg*16 + n%16
+// holds 8 consecutive k.  Inside every PAIR of k-tiles (64 k values = 2 tiles x 4 lane groups x 8) the 8-element
+// chunks are dealt so that tile t (0/1) of pair p, lane group kg holds
+//     k = 64 p + 32 (kg >> 1) + 8 (2 (kg & 1) + t) ... + 7.
+// Reason (linear_skinny_kernel): with at most 8 utterances a wave fetches the activations of a whole pair with ONE
+// all-lanes load of eight full cache lines (lane = kt*32 + g*8 + row reads x[row][64p + 32kt + 8g ..]); used
+// directly as the MFMA B operand that register is column (g&1)*8 + row, lane group kt*2 + (g>>1), i.e. columns 0-7
+// carry exactly the chunks of tile 0 and columns 8-15 those of tile 1.  An unpaired last k-tile (K/32 odd) keeps
+// the plain order k = 32 j + 8 kg.  A reduction may take its k values in any order as long as both operands agree.
+__host__ __device__ inline int packed_k0(int j, int kg, int KT) {  // first k of lane group kg in k-tile j
+  if (j < (KT & ~1)) return (j >> 1) * 64 + (kg >> 1) * 32 + (((kg & 1) << 1) + (j & 1)) * 8;
+  return j * 32 + kg * 8;
+}
+
 __device__ inline int64_t packed_index(int n, int k, int KT) {
-  // tile (n/16, k/32); inside: lane = (k%32/8)*16 + n%16, element k%8
-  int lane = ((k & 31) >> 3) * 16 + (n & 15);
-  return ((int64_t)(n >> 4) * KT + (k >> 5)) * 512 + lane * 8 + (k & 7);
+  int j, kg;
+  if ((k >> 5) < (KT & ~1)) {
+    const int kt = (k >> 5) & 1, g = (k >> 3) & 3;
+    j = ((k >> 6) << 1) + (g & 1);
+    kg = kt * 2 + (g >> 1);
+  } else {
+    j = k >> 5;
+    kg = (k >> 3) & 3;
+  }
+  return ((int64_t)(n >> 4) * KT + j) * 512 + (kg * 16 + (n & 15)) * 8 + (k & 7);
 }
 
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K,
@@ -210,9 +231,16 @@ int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf
 // skinny linear (M <= 16): weight-streaming MFMA GEMV
 // =====================================================================================
 //
-// Work-group = WAVES waves, owns TILES 16-row weight tiles over the whole K; wave w owns the k-tiles
-// [w*KT/WAVES, (w+1)*KT/WAVES).  Per k-tile a lane issues one 16-byte weight load (the wave: one
-// contiguous 1 KiB tile) and one 16-byte activation load (L2-resident), then one MFMA per tile.
+// Work-group = WAVES waves, owns TILES 16-row weight tiles over the whole K; wave w owns the k-tile PAIRS
+// [w*P/WAVES, (w+1)*P/WAVES) (P = K/64; the last wave also takes an unpaired last tile).  Per pair a lane issues
+// two 16-byte weight loads per tile (the wave: two contiguous 1 KiB tiles) and the activation fragments:
+//   M <= 8 (PAIRX): ONE all-lanes load of eight full cache lines for the whole pair (see packed_k0), used as the B
+//                   operand of both tiles; tile 0 accumulates in acc0 (valid in columns 0-7), tile 1 in acc1 (valid
+//                   in columns 8-15), acc1 is shifted down 8 columns (DPP row_shl) and added at the end;
+//   M  > 8        : one load per tile (16 rows x 64 B), tile 0 -> acc0, tile 1 -> acc1, added at the end.
+// Both variants multiply the same values in the same order, so a row's result does not depend on the batch it is in.
+// What bounds this kernel is requests in flight per CU, not bytes (tools/gemv_lds_probe.hip): halving the activation
+// requests took w1|w3 21.8 -> 20.6, wqkv 10.4 -> 9.8, wo 7.1 -> 6.5, w2 14.7 -> 13.3 us.
 // Split-K partials meet in LDS and are summed in wave order (deterministic).
 
 __device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -223,8 +251,13 @@ __device__ inline u32x4 wload(const u32x4* p) {
   return *p;
 }
 
-// TILES = 16-row weight tiles per work-group (SwiGLU: gate/up tiles alternate, so TILES is even).
-template <int WAVES, int EPI, bool NORM, int UNR, int TILES = (EPI == EPI_SILU ? 2 : 1), bool NT = true>
+__device__ inline float dpp_row_shl8(float v) {  // lane n of every 16-lane row receives lane n + 8
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x108, 0xf, 0xf, false));
+}
+
+// UNR = k-tile pairs in flight per wave; TILES = 16-row weight tiles per work-group (SwiGLU: gate/up tiles
+// alternate, so TILES is even); PAIRX = the M <= 8 activation path.
+template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool PAIRX, bool NT = true>
 __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a) {
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
   __shared__ float red[WAVES][TILES][256];
@@ -232,92 +265,133 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = lane & 15, g = lane >> 4;
-  const int KT = a.K >> 5;
+  const int KT = a.K >> 5, P = KT >> 1;
   const int tile0 = blockIdx.x * TILES;
   const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
 
-  const int kbeg = (int)((int64_t)wave * KT / WAVES), kend = (int)((int64_t)(wave + 1) * KT / WAVES);
+  const int pbeg = (int)((int64_t)wave * P / WAVES), pend = (int)((int64_t)(wave + 1) * P / WAVES);
   const u32x4* wrow[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) wrow[t] = wp + ((int64_t)(tile0 + t) * KT) * 64 + lane;
 
   // the first chunk of weight tiles is issued BEFORE the RMSNorm prologue so that HBM latency overlaps
   // the row statistics
-  u32x4 wa[TILES][UNR];
-  const int nfull = (kend - kbeg) / UNR;
-  if (nfull > 0) {
+  u32x4 wa[TILES][UNR][2];
+  const int nfull = (pend - pbeg) / UNR;
+  auto load_chunk = [&](int p0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) wa[t][u] = wload<NT>(wrow[t] + (int64_t)(kbeg + u) * 64);
-  }
+      for (int t = 0; t < TILES; ++t) {
+        wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u)) * 64);
+        wa[t][u][1] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u) + 1) * 64);
+      }
+  };
+  if (nfull > 0) load_chunk(pbeg);
 
-  float rstd = 0.f;
   if (NORM) {
     for (int r = wave; r < a.M; r += WAVES) {
       float v = row_rstd(a.x + (int64_t)r * a.ldx, a.K, a.eps, lane);
       if (lane == 0) s_rstd[r] = v;
     }
     __syncthreads();
-    if (b < a.M) rstd = s_rstd[b];
   }
 
-  const bool bvalid = b < a.M;
-  const bf16_t* xrow = a.x + (int64_t)(bvalid ? b : 0) * a.ldx + g * 8;
-  const bf16_t* nrow = NORM ? a.norm_w + g * 8 : nullptr;
+  // activation fragment addressing
+  //   PAIRX: fetch lane = kt*32 + g'*8 + row  -> x[row][64 p + 32 kt + 8 g' ..]; as operand: column (g'&1)*8 + row
+  //   else : operand lane (b, g) of tile t    -> x[b][packed_k0(2p + t, g) ..]
+  const int f_row = PAIRX ? min(lane & 7, a.M - 1) : (b < a.M ? b : 0);
+  const bool bvalid = PAIRX ? true : b < a.M;
+  const int f_off = PAIRX ? (lane >> 5) * 32 + ((lane >> 3) & 3) * 8 : 0;
+  const bf16_t* xrow = a.x + (int64_t)f_row * a.ldx + f_off;
+  const bf16_t* nrow = NORM ? a.norm_w + f_off : nullptr;
+  const float rstd = NORM ? s_rstd[f_row] : 0.f;
+  const int k0_t0 = (g >> 1) * 32 + ((g & 1) << 1) * 8, k0_t1 = k0_t0 + 8;  // packed_k0 inside a pair, tile 0 / 1
 
-  f32x4 acc[TILES];
+  f32x4 acc0[TILES], acc1[TILES];
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < TILES; ++t) {
+    acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
-  auto compute_chunk = [&](u32x4 (&wv)[TILES][UNR], int kt) {
-    uint4 xv[UNR], nv[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      xv[u] = bvalid ? *reinterpret_cast<const uint4*>(xrow + (kt + u) * 32) : make_uint4(0, 0, 0, 0);
-      if (NORM) nv[u] = *reinterpret_cast<const uint4*>(nrow + (kt + u) * 32);
+  auto frag = [&](int koff) -> bf16x8 {  // activation (optionally normalised) fragment starting at element koff
+    uint4 xv = bvalid ? *reinterpret_cast<const uint4*>(xrow + koff) : make_uint4(0, 0, 0, 0);
+    if (NORM) {
+      uint4 nv = *reinterpret_cast<const uint4*>(nrow + koff);
+      return norm_frag(xv, nv, rstd);
     }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      bf16x8 xb;
-      if (NORM) xb = norm_frag(xv[u], nv[u], rstd);
-      else xb = *reinterpret_cast<bf16x8*>(&xv[u]);
-#pragma unroll
-      for (int t = 0; t < TILES; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[t][u]), xb, acc[t], 0, 0, 0);
-    }
+    return *reinterpret_cast<bf16x8*>(&xv);
   };
-  auto load_chunk = [&](u32x4 (&wv)[TILES][UNR], int kt) {
+  auto compute_chunk = [&](int p0) {
+    bf16x8 x0[UNR], x1[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int kb = (p0 + u) * 64;
+      if (PAIRX) {
+        x0[u] = frag(kb);
+        x1[u] = x0[u];
+      } else {
+        x0[u] = frag(kb + k0_t0);
+        x1[u] = frag(kb + k0_t1);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) wv[t][u] = wload<NT>(wrow[t] + (int64_t)(kt + u) * 64);
+      for (int t = 0; t < TILES; ++t) {
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][u][0]), x0[u], acc0[t], 0, 0, 0);
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][u][1]), x1[u], acc1[t], 0, 0, 0);
+      }
   };
 
-  int kt = kbeg;
+  int p = pbeg;
   for (int c = 0; c < nfull; ++c) {
-    compute_chunk(wa, kt);
-    kt += UNR;
-    if (c + 1 < nfull) load_chunk(wa, kt);
+    compute_chunk(p);
+    p += UNR;
+    if (c + 1 < nfull) load_chunk(p);
   }
-  for (; kt < kend; ++kt) {
-    uint4 xv = bvalid ? *reinterpret_cast<const uint4*>(xrow + kt * 32) : make_uint4(0, 0, 0, 0);
+  for (; p < pend; ++p) {  // leftover pairs of this wave, one at a time
+    bf16x8 x0, x1;
+    if (PAIRX) {
+      x0 = frag(p * 64);
+      x1 = x0;
+    } else {
+      x0 = frag(p * 64 + k0_t0);
+      x1 = frag(p * 64 + k0_t1);
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      u32x4 w0 = wload<NT>(wrow[t] + (int64_t)(2 * p) * 64), w1 = wload<NT>(wrow[t] + (int64_t)(2 * p + 1) * 64);
+      acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), x0, acc0[t], 0, 0, 0);
+      acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), x1, acc1[t], 0, 0, 0);
+    }
+  }
+  // fold the two accumulators: PAIRX keeps tile 1's sums in columns 8-15 of the same rows
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0[t][j] += PAIRX ? dpp_row_shl8(acc1[t][j]) : acc1[t][j];
+  if ((KT & 1) && wave == WAVES - 1) {  // unpaired last k-tile (plain k order), after the fold: same in both variants
+    const int kt = KT - 1;
+    const int row = b < a.M ? b : 0;
+    uint4 xv = *reinterpret_cast<const uint4*>(a.x + (int64_t)row * a.ldx + kt * 32 + g * 8);
     bf16x8 xb;
     if (NORM) {
-      uint4 nv = *reinterpret_cast<const uint4*>(nrow + kt * 32);
-      xb = norm_frag(xv, nv, rstd);
+      uint4 nv = *reinterpret_cast<const uint4*>(a.norm_w + kt * 32 + g * 8);
+      xb = norm_frag(xv, nv, s_rstd[row]);
     } else {
       xb = *reinterpret_cast<bf16x8*>(&xv);
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
       u32x4 wv = wload<NT>(wrow[t] + (int64_t)kt * 64);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[t], 0, 0, 0);
+      acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc0[t], 0, 0, 0);
     }
   }
 
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[t];
+  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc0[t];
   __syncthreads();
 
   if (tid < 256) {
@@ -354,103 +428,16 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
   }
 }
 
-// "Burst" variant for the case where a wave's whole K slice fits in registers (KTW k-tiles per wave,
-// K = 32 * WAVES * KTW): every weight tile of the wave is requested before anything else happens, so the
-// HBM stream runs at full depth while the RMSNorm row statistics (an L2 round trip + reduction) are
-// computed, instead of stalling behind them.
-template <int WAVES, int EPI, bool NORM, int KTW, int TILES>
-__global__ __launch_bounds__(WAVES * 64) void linear_skinny_burst_kernel(LinearArgs a) {
-  static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
-  __shared__ float red[WAVES][TILES][256];
-  __shared__ float s_rstd[16];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = lane & 15, g = lane >> 4;
-  constexpr int KT = WAVES * KTW;
-  const int tile0 = blockIdx.x * TILES;
-  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
-  const int kbeg = wave * KTW;
-
-  u32x4 wv[TILES][KTW];
-#pragma unroll
-  for (int u = 0; u < KTW; ++u)
-#pragma unroll
-    for (int t = 0; t < TILES; ++t)
-      wv[t][u] = __builtin_nontemporal_load(wp + ((int64_t)(tile0 + t) * KT + kbeg + u) * 64 + lane);
-
-  float rstd = 0.f;
-  if (NORM) {
-    for (int r = wave; r < a.M; r += WAVES) {
-      float v = row_rstd(a.x + (int64_t)r * a.ldx, a.K, a.eps, lane);
-      if (lane == 0) s_rstd[r] = v;
-    }
-    __syncthreads();
-    if (b < a.M) rstd = s_rstd[b];
-  }
-  const bool bvalid = b < a.M;
-  const bf16_t* xrow = a.x + (int64_t)(bvalid ? b : 0) * a.ldx + g * 8;
-  const bf16_t* nrow = NORM ? a.norm_w + g * 8 : nullptr;
-
-  f32x4 acc[TILES];
-#pragma unroll
-  for (int t = 0; t < TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < KTW; ++u) {
-    uint4 xv = bvalid ? *reinterpret_cast<const uint4*>(xrow + (kbeg + u) * 32) : make_uint4(0, 0, 0, 0);
-    bf16x8 xb;
-    if (NORM) {
-      uint4 nv = *reinterpret_cast<const uint4*>(nrow + (kbeg + u) * 32);
-      xb = norm_frag(xv, nv, rstd);
-    } else {
-      xb = *reinterpret_cast<bf16x8*>(&xv);
-    }
-#pragma unroll
-    for (int t = 0; t < TILES; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[t][u]), xb, acc[t], 0, 0, 0);
-  }
-
-#pragma unroll
-  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[t];
-  __syncthreads();
-  if (tid < 256) {
-    const int bb = tid >> 4, r = tid & 15;
-    if (bb < a.M) {
-      const int ridx = (((r >> 2) * 16) + bb) * 4 + (r & 3);
-      float v[TILES];
-#pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) sacc += red[w][t][ridx];
-        v[t] = sacc;
-      }
-      if (EPI == EPI_STORE) {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) a.out[(int64_t)bb * a.ldo + (tile0 + t) * 16 + r] = f2bf(v[t]);
-      } else if (EPI == EPI_RESIDUAL) {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-          const int n = (tile0 + t) * 16 + r;
-          a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + rbf(v[t]));
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < TILES; t += 2) {
-          const int n = ((tile0 + t) >> 1) * 16 + r;
-          float gate = rbf(silu_f(rbf(v[t])));
-          float up = rbf(v[t + 1 < TILES ? t + 1 : t]);
-          a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
-        }
-      }
-    }
-  }
-}
-
 template <int WAVES, int UNR, int TILES>
 static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
   const bool norm = a.norm_w != nullptr;
+  const bool pairx = a.M <= 8;
   dim3 grid(a.N / (16 * TILES)), block(WAVES * 64);
-#define FMI_LAUNCH(EPI_, NORM_) \
-  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true>), grid, block, 0, s, a)
+#define FMI_LAUNCH(EPI_, NORM_)                                                                                     \
+  do {                                                                                                              \
+    if (pairx) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, false>), grid, block, 0, s, a);   \
+  } while (0)
   if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH(EPI_STORE, true); else FMI_LAUNCH(EPI_STORE, false); }
   else if (a.epi == EPI_RESIDUAL) { if (norm) FMI_LAUNCH(EPI_RESIDUAL, true); else FMI_LAUNCH(EPI_RESIDUAL, false); }
   else if constexpr (TILES % 2 == 0) { if (norm) FMI_LAUNCH(EPI_SILU, true); else FMI_LAUNCH(EPI_SILU, false); }
@@ -459,11 +446,11 @@ static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
   return FMI_OK;
 }
 
-// Variant choice from tools/gemv_bench.hip on MI355X (profiles/gemv_bench_r01.txt), M = 8:
-//   w13  (19456x2560, norm, SwiGLU)  8 waves, UNR 2, 2 tiles : 21.8 us (4.56 TB/s)
-//   wqkv (6144x2560, norm)           8 waves, UNR 2, 2 tiles : 10.0 us (3.16 TB/s)
-//   wo   (2560x4096, residual)       8 waves, UNR 4, 1 tile  :  6.7 us (3.11 TB/s)
-//   w2   (2560x9728, residual)       8 waves, UNR 4, 1 tile  : 13.4 us (3.73 TB/s)
+// Variant choice from tools/gemv_bench.hip on MI355X (profiles/gemv_bench_r01.txt), M = 8; UNR counts k-tile pairs:
+//   w13  (19456x2560, norm, SwiGLU)  8 waves, 1 pair,  2 tiles
+//   wqkv (6144x2560, norm)           8 waves, 1 pair,  2 tiles
+//   wo   (2560x4096, residual)       8 waves, 2 pairs, 1 tile
+//   w2   (2560x9728, residual)       8 waves, 2 pairs, 1 tile
 // A bare streaming read of the same bytes per launch reaches 3.6 / 4.1 / 4.4 / 5.1 TB/s at
 // 21 / 32 / 50 / 100 MiB (about 3 us of every launch is ramp), 6.4-6.6 TB/s at 1 GiB.
 // (The norm-fused variants were VALU-bound on software bf16 rounding until norm_frag moved to
@@ -478,12 +465,12 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
     if (a.epi == EPI_SILU || ntile % 2 == 0) return launch_skinny_t<4, 1, 2>(a, s);
     return launch_skinny_t<4, 1, 1>(a, s);
   }
-  if (a.epi == EPI_SILU) return launch_skinny_t<8, 2, 2>(a, s);
+  if (a.epi == EPI_SILU) return launch_skinny_t<8, 1, 2>(a, s);
   if (a.norm_w) {  // norm-fused projections (wqkv, fast_output)
-    if (ntile % 2 == 0) return launch_skinny_t<8, 2, 2>(a, s);
-    return launch_skinny_t<8, 2, 1>(a, s);
+    if (ntile % 2 == 0) return launch_skinny_t<8, 1, 2>(a, s);
+    return launch_skinny_t<8, 1, 1>(a, s);
   }
-  return launch_skinny_t<8, 4, 1>(a, s);  // wo, w2, LM head
+  return launch_skinny_t<8, 2, 1>(a, s);  // wo, w2, LM head
 }
 
 // =====================================================================================
@@ -507,7 +494,7 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(LinearArgs a) {
   for (int tm = 0; tm < 4; ++tm) {
     int m = m0 + tm * 16 + mi;
     if (m >= a.M) m = a.M - 1;
-    xrow[tm] = a.x + (int64_t)m * a.ldx + g * 8;
+    xrow[tm] = a.x + (int64_t)m * a.ldx;
   }
   int ntile[4];
 #pragma unroll
@@ -524,7 +511,7 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(LinearArgs a) {
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) wv[tn] = wp[((int64_t)ntile[tn] * KT + kt) * 64 + lane];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) xv[tm] = *reinterpret_cast<const uint4*>(xrow[tm] + kt * 32);
+    for (int tm = 0; tm < 4; ++tm) xv[tm] = *reinterpret_cast<const uint4*>(xrow[tm] + packed_k0(kt, g, KT));
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll

@@ -82,6 +82,29 @@ def test_skinny_linear_s2_shapes_and_batch_invariance(lib, N, K):
     assert torch.equal(one[0], full[3])
 
 
+@pytest.mark.parametrize("N,K,epi,norm", [(19456, 2560, 2, True), (6144, 2560, 0, True), (2560, 4096, 1, False),
+                                          (2560, 9728, 1, False), (4112, 2560, 0, True), (2560, 2080, 1, True),
+                                          (192, 256, 0, True), (320, 96, 2, False)])
+def test_skinny_linear_row_result_is_independent_of_the_batch_size(lib, N, K, epi, norm):
+    """Up to 8 rows the GEMV fetches the activation fragments of a k-tile pair with one all-lanes load and keeps
+    the two tiles' sums in the two column halves of the MFMA; above 8 rows it loads per tile.  Both must give every
+    row the same bits (same products, same order): a row computed alone, in a batch of 8 and in a batch of 13,
+    at the S2-Pro shapes, an odd tile count, an odd number of k-tiles (2080 = 65, 96 = 3) and tiny shapes."""
+    g = torch.Generator().manual_seed(N * 3 + K)
+    x = torch.randn(13, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16() if norm else None
+    res = torch.randn(13, N if epi != 2 else N // 2, generator=g).bfloat16() if epi == 1 else None
+    big = _linear(lib, x, w, nw, res, 13, N, K, epi, 1)
+    ok, mx, nbad = bf16_close(big, _linear_oracle(x, w, nw, res, epi), scale=res)
+    assert ok, (mx, nbad)
+    eight = _linear(lib, x[:8].contiguous(), w, nw, None if res is None else res[:8].contiguous(), 8, N, K, epi, 1)
+    assert torch.equal(eight, big[:8])
+    for r in (0, 5, 12):
+        one = _linear(lib, x[r:r + 1].contiguous(), w, nw, None if res is None else res[r:r + 1].contiguous(), 1, N, K, epi, 1)
+        assert torch.equal(one[0], big[r]), r
+
+
 def _sample(lib, logits, ids, samp, frame, draw, prev, sem):
     from fish_speech_amd._lib import SamplingC, check
 

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restric
 
 struct Shape { const char* name; int N, K, epi; bool norm; };
 
-template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool NT>
+template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool NT, bool PX = true>
 float run_variant(const Shape& sh, std::vector<bf16_t*>& wbufs, bf16_t* x, bf16_t* nw, bf16_t* res, bf16_t* out, int M, int iters) {
   LinearArgs a{};
   a.x = x; a.ldx = sh.K; a.norm_w = NORM ? nw : nullptr; a.eps = 1e-6f; a.res = res; a.M = M; a.N = sh.N; a.K = sh.K; a.epi = EPI;
@@ -35,41 +35,24 @@ float run_variant(const Shape& sh, std::vector<bf16_t*>& wbufs, bf16_t* x, bf16_
   if ((sh.N / 16) % TILES) return -1.f;
   dim3 grid(sh.N / (16 * TILES)), block(WAVES * 64);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) { a.wp = wbufs[w % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, NT>), grid, block, 0, 0, a); }
+  for (int w = 0; w < 3; ++w) { a.wp = wbufs[w % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, PX, NT>), grid, block, 0, 0, a); }
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) { a.wp = wbufs[i % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, NT>), grid, block, 0, 0, a); }
+  for (int i = 0; i < iters; ++i) { a.wp = wbufs[i % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, PX, NT>), grid, block, 0, 0, a); }
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   return ms * 1e3f / iters;
 }
-
-template <int WAVES, int EPI, bool NORM, int KTW, int TILES>
-float run_burst(const Shape& sh, std::vector<bf16_t*>& wbufs, bf16_t* x, bf16_t* nw, bf16_t* res, bf16_t* out, int M, int iters) {
-  if (sh.K != 32 * WAVES * KTW || (sh.N / 16) % TILES) return -1.f;
-  LinearArgs a{};
-  a.x = x; a.ldx = sh.K; a.norm_w = NORM ? nw : nullptr; a.eps = 1e-6f; a.res = res; a.M = M; a.N = sh.N; a.K = sh.K; a.epi = EPI;
-  const int n_out = EPI == EPI_SILU ? sh.N / 2 : sh.N;
-  a.ldr = n_out; a.out = out; a.ldo = n_out;
-  dim3 grid(sh.N / (16 * TILES)), block(WAVES * 64);
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) { a.wp = wbufs[w % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_burst_kernel<WAVES, EPI, NORM, KTW, TILES>), grid, block, 0, 0, a); }
-  CK(hipDeviceSynchronize());
-  CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) { a.wp = wbufs[i % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_burst_kernel<WAVES, EPI, NORM, KTW, TILES>), grid, block, 0, 0, a); }
-  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  return ms * 1e3f / iters;
-}
-#define BU(W, KTW, T) do { float us = (sh.epi == EPI_SILU) ? run_burst<W, EPI_SILU, true, KTW, (T < 2 ? 2 : T)>(sh, wbufs, x, nw, res, out, M, iters) \
-    : (sh.epi == EPI_RESIDUAL ? run_burst<W, EPI_RESIDUAL, false, KTW, T>(sh, wbufs, x, nw, res, out, M, iters) \
-    : run_burst<W, EPI_STORE, true, KTW, T>(sh, wbufs, x, nw, res, out, M, iters)); \
-    if (us > 0) { printf("  BURST W=%2d KTW=%2d TILES=%d : %7.2f us  %6.0f GB/s\n", W, KTW, (sh.epi == EPI_SILU && T < 2) ? 2 : T, us, bytes / us * 1e-3); fflush(stdout); } } while (0)
 
 #define V(W, U, T, NTF) do { float us = (sh.epi == EPI_SILU) ? run_variant<W, EPI_SILU, true, U, (T < 2 ? 2 : T), NTF>(sh, wbufs, x, nw, res, out, M, iters) \
     : (sh.epi == EPI_RESIDUAL ? run_variant<W, EPI_RESIDUAL, false, U, T, NTF>(sh, wbufs, x, nw, res, out, M, iters) \
     : run_variant<W, EPI_STORE, true, U, T, NTF>(sh, wbufs, x, nw, res, out, M, iters)); \
-    if (us > 0) { printf("  W=%2d UNR=%d TILES=%d nt=%d : %7.2f us  %6.0f GB/s\n", W, U, (sh.epi == EPI_SILU && T < 2) ? 2 : T, (int)NTF, us, bytes / us * 1e-3); fflush(stdout); } } while (0)
+    if (us > 0) { printf("  W=%2d PAIRS=%d TILES=%d nt=%d : %7.2f us  %6.0f GB/s\n", W, U, (sh.epi == EPI_SILU && T < 2) ? 2 : T, (int)NTF, us, bytes / us * 1e-3); fflush(stdout); } } while (0)
+
+#define VX(W, U, T) do { float a_ = (sh.epi == EPI_SILU) ? run_variant<W, EPI_SILU, true, U, (T < 2 ? 2 : T), true, false>(sh, wbufs, x, nw, res, out, M, iters) \
+    : (sh.epi == EPI_RESIDUAL ? run_variant<W, EPI_RESIDUAL, false, U, T, true, false>(sh, wbufs, x, nw, res, out, M, iters) \
+    : run_variant<W, EPI_STORE, true, U, T, true, false>(sh, wbufs, x, nw, res, out, M, iters)); \
+    if (a_ > 0) { printf("  W=%2d PAIRS=%d TILES=%d per-tile activation loads : %7.2f us\n", W, U, T, a_); fflush(stdout); } } while (0)
 
 int main() {
   const int M = 8, iters = 200;
@@ -105,14 +88,7 @@ int main() {
     CK(hipMalloc((void**)&res, (size_t)16 * sh.N * 2)); CK(hipMemset(res, 0, (size_t)16 * sh.N * 2));
     CK(hipMalloc((void**)&out, (size_t)16 * sh.N * 2));
     printf("%s  (%.1f MB, M=%d)\n", sh.name, bytes / 1e6, M);
-    BU(16, 5, 1); BU(16, 5, 2); BU(16, 5, 4); BU(8, 10, 1); BU(8, 10, 2); BU(10, 8, 2); BU(10, 8, 1); BU(16, 8, 1); BU(16, 8, 2); BU(8, 16, 1); BU(16, 19, 1); BU(8, 38, 1); BU(4, 20, 1); BU(4, 20, 2);
-    V(8, 2, 2, true); V(16, 2, 2, true); V(16, 2, 1, true); V(8, 4, 1, true);
-    if (getenv("TILES4")) { V(8, 2, 4, true); V(8, 1, 4, true); V(16, 1, 4, true); V(16, 2, 4, true); V(4, 2, 4, true); V(8, 4, 4, true); V(8, 1, 2, true); V(8, 3, 2, true); }
-    if (getenv("FULL_SWEEP")) {
-    V(4, 4, 1, true); V(4, 4, 2, true); V(4, 4, 4, true); V(4, 8, 1, true); V(4, 8, 2, true); V(4, 2, 2, true); V(4, 4, 2, false);
-    V(2, 4, 2, true); V(2, 8, 2, true); V(2, 4, 4, true); V(1, 4, 4, true); V(1, 8, 4, true); V(1, 8, 2, true);
-    V(8, 4, 1, true); V(8, 4, 2, true); V(8, 2, 2, true); V(8, 8, 2, true); V(16, 4, 1, true); V(16, 2, 1, true); V(16, 2, 2, true); V(16, 4, 2, true);
-    }
+    V(8, 1, 2, true); VX(8, 1, 2); V(8, 2, 1, true); VX(8, 2, 1); V(8, 1, 2, true); VX(8, 1, 2); V(8, 2, 1, true); VX(8, 2, 1);
     for (auto p : wbufs) hipFree(p);
     hipFree(x); hipFree(nw); hipFree(res); hipFree(out);
   }
