@@ -88,7 +88,9 @@ int main() {
     CK(hipMalloc((void**)&res, (size_t)16 * sh.N * 2)); CK(hipMemset(res, 0, (size_t)16 * sh.N * 2));
     CK(hipMalloc((void**)&out, (size_t)16 * sh.N * 2));
     printf("%s  (%.1f MB, M=%d)\n", sh.name, bytes / 1e6, M);
-    V(8, 1, 2, true); VX(8, 1, 2); V(8, 2, 1, true); VX(8, 2, 1); V(8, 1, 2, true); VX(8, 1, 2); V(8, 2, 1, true); VX(8, 2, 1);
+    // paired activation loads (the M <= 8 path) over pairs-in-flight x tiles, then the per-tile-load path (M > 8) of the shipped shapes
+    V(8, 1, 2, true); V(8, 2, 2, true); V(8, 1, 1, true); V(8, 2, 1, true); V(8, 4, 1, true); V(16, 1, 2, true); V(16, 2, 1, true);
+    VX(8, 1, 2); VX(8, 2, 1);
     for (auto p : wbufs) hipFree(p);
     hipFree(x); hipFree(nw); hipFree(res); hipFree(out);
   }
