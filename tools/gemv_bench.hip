@@ -49,6 +49,21 @@ float run_variant(const Shape& sh, std::vector<bf16_t*>& wbufs, bf16_t* x, bf16_
     : run_variant<W, EPI_STORE, true, U, T, NTF>(sh, wbufs, x, nw, res, out, M, iters)); \
     if (us > 0) { printf("  W=%2d PAIRS=%d TILES=%d nt=%d : %7.2f us  %6.0f GB/s\n", W, U, (sh.epi == EPI_SILU && T < 2) ? 2 : T, (int)NTF, us, bytes / us * 1e-3); fflush(stdout); } } while (0)
 
+static float run_shipped(const Shape& sh, std::vector<bf16_t*>& wbufs, bf16_t* x, bf16_t* nw, bf16_t* res, bf16_t* out, int M, int iters) {
+  LinearArgs a{};
+  a.x = x; a.ldx = sh.K; a.norm_w = sh.norm ? nw : nullptr; a.eps = 1e-6f; a.res = res; a.M = M; a.N = sh.N; a.K = sh.K; a.epi = sh.epi;
+  const int n_out = sh.epi == EPI_SILU ? sh.N / 2 : sh.N;
+  a.ldr = n_out; a.out = out; a.ldo = n_out;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) { a.wp = wbufs[w % wbufs.size()]; launch_linear_skinny(a, 0); }
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) { a.wp = wbufs[i % wbufs.size()]; launch_linear_skinny(a, 0); }
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / iters;
+}
+
 #define VX(W, U, T) do { float a_ = (sh.epi == EPI_SILU) ? run_variant<W, EPI_SILU, true, U, (T < 2 ? 2 : T), true, false>(sh, wbufs, x, nw, res, out, M, iters) \
     : (sh.epi == EPI_RESIDUAL ? run_variant<W, EPI_RESIDUAL, false, U, T, true, false>(sh, wbufs, x, nw, res, out, M, iters) \
     : run_variant<W, EPI_STORE, true, U, T, true, false>(sh, wbufs, x, nw, res, out, M, iters)); \
@@ -91,6 +106,7 @@ int main() {
     // paired activation loads (the M <= 8 path) over pairs-in-flight x tiles, then the per-tile-load path (M > 8) of the shipped shapes
     V(8, 1, 2, true); V(8, 2, 2, true); V(8, 1, 1, true); V(8, 2, 1, true); V(8, 4, 1, true); V(16, 1, 2, true); V(16, 2, 1, true);
     VX(8, 1, 2); VX(8, 2, 1);
+    { float us = run_shipped(sh, wbufs, x, nw, res, out, M, iters); printf("  shipped launcher (launch_linear_skinny) : %7.2f us  %6.0f GB/s\n", us, bytes / us * 1e-3); }
     for (auto p : wbufs) hipFree(p);
     hipFree(x); hipFree(nw); hipFree(res); hipFree(out);
   }
