@@ -91,7 +91,8 @@ int main() {
     printf("stream read %zu MiB per launch: %.2f us/launch, %.0f GB/s\n", mb, ms * 10, bytes * 100 / (ms * 1e-3) * 1e-9);
   }
   Shape shapes[] = {{"w13  N=19456 K=2560 swiglu+norm", 19456, 2560, EPI_SILU, true}, {"wqkv N=6144 K=2560 store+norm", 6144, 2560, EPI_STORE, true},
-                    {"wo   N=2560 K=4096 residual", 2560, 4096, EPI_RESIDUAL, false}, {"w2   N=2560 K=9728 residual", 2560, 9728, EPI_RESIDUAL, false}};
+                    {"wo   N=2560 K=4096 residual", 2560, 4096, EPI_RESIDUAL, false}, {"w2   N=2560 K=9728 residual", 2560, 9728, EPI_RESIDUAL, false},
+                    {"head N=4096 K=2560 store+norm (fast_output / live LM head)", 4096, 2560, EPI_STORE, true}};
   for (const Shape& sh : shapes) {
     const double bytes = (double)sh.N * sh.K * 2;
     const int nbuf = (int)(2.0e9 / bytes) + 1;
