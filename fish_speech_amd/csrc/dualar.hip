@@ -952,7 +952,7 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
   a.wp = packed; a.x = (const bf16_t*)x_dev; a.ldx = K; a.norm_w = (const bf16_t*)norm_w_dev; a.eps = eps;
   a.res = (const bf16_t*)residual_dev; a.ldr = n_out; a.out = (bf16_t*)out_dev; a.ldo = n_out; a.M = M; a.N = N;
   a.K = K; a.epi = epilogue;
-  const bool skinny = force_path == 1 || (force_path == 0 && M <= 16);
+  const bool skinny = force_path == 1 || (force_path == 0 && M <= 16);  // 2: tiled (LDS-staged), 5: tiled, operands straight from L2
   if (rc == FMI_OK) {
     if (skinny) {
       rc = launch_linear_skinny(a, s);
@@ -963,7 +963,7 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
         a.x = xn;
         a.norm_w = nullptr;
       }
-      if (rc == FMI_OK) rc = launch_linear_tiled(a, s);
+      if (rc == FMI_OK) rc = launch_linear_tiled(a, s, force_path == 5);
     }
   }
   hipStreamSynchronize(s);

@@ -52,7 +52,7 @@ struct LinearArgs {
   int epi;
 };
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s);  // M <= 16
-int launch_linear_tiled(const LinearArgs& a, hipStream_t s);   // any M, no fused norm
+int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct = false);  // any M, no fused norm
 int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf16_t* out, int ldo,
                         int M, int K, hipStream_t s, bf16_t* out2 = nullptr);
 

@@ -115,8 +115,20 @@ __global__ void embed_kernel(EmbedArgs a) {
     float vq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) vq[j] = 0.f;
-    if (sem) {
-      for (int i = 0; i < a.ncb; ++i) {
+    if (sem) {  // all codebook rows are requested before the first is summed (one memory round trip, not ncb)
+      constexpr int MAXCB = 16;
+      uint4 cv[MAXCB];
+#pragma unroll
+      for (int i = 0; i < MAXCB; ++i)
+        if (i < a.ncb) cv[i] = *reinterpret_cast<const uint4*>(a.cb_emb + (int64_t)(tok[i + 1] + i * a.cbs) * a.dim + d);
+#pragma unroll
+      for (int i = 0; i < MAXCB; ++i)
+        if (i < a.ncb) {
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&cv[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vq[j] += bf2f(e[j]);
+        }
+      for (int i = MAXCB; i < a.ncb; ++i) {
         uint4 v = *reinterpret_cast<const uint4*>(a.cb_emb + (int64_t)(tok[i + 1] + i * a.cbs) * a.dim + d);
         const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
 #pragma unroll
@@ -563,11 +575,142 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(LinearArgs a) {
   }
 }
 
-int launch_linear_tiled(const LinearArgs& a, hipStream_t s) {
+// LDS-staged variant of the prefill GEMM (default).  The direct variant above feeds every MFMA from L2
+// (8 wave-loads per 16 MFMAs per wave: 17 % of the bf16 peak at M = 1600); here a 128 x 128 output tile shares its
+// operands through LDS: per k-step (2 k-tiles = 64 k) 16 KiB of weights arrive by linear LDS-DMA (the packed
+// layout already is fragment order) and 16 KiB of activations by per-lane DMA (lane (row, kg) fetches the 16
+// bytes the B operand lane needs, packed_k0 map), double-buffered, one barrier per k-step; the operands are read
+// back with ds_read_b128 at lane*16 (conflict-free).  LDS reads are inline asm so that the compiler does not drain
+// the in-flight DMA of the next step before every read (cf. tools/gemv_lds_probe.hip).  Same MFMA order per
+// output element as the direct variant: identical results.
+__device__ inline u32x4 lds_read_b128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][A 16 pieces | B 16 pieces] x 1 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int KT = a.K >> 5, KS = (KT + 1) >> 1;  // k-steps of two k-tiles (the last may hold one)
+  const int NT = a.N >> 4;
+  const int n_blk0 = blockIdx.x * 8, m_blk0 = blockIdx.y * 128;
+  const int mi = lane & 15, g = lane >> 4;
+  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
+
+  auto stage = [&](int ks, int buf) {
+    char* base = smem + buf * 32768;
+    for (int p = wave; p < 32; p += 4) {       // pieces 0-15: weights, 16-31: activations; piece = tile*2 + kk
+      const int kk = p & 1, j = 2 * ks + kk;
+      if (j >= KT) continue;                   // unpaired last k-tile: second half of the step is empty
+      if (p < 16) {
+        const int nt = min(n_blk0 + (p >> 1), NT - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + ((int64_t)nt * KT + j) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+      } else {
+        const int mt = (p - 16) >> 1;
+        const int m = min(m_blk0 + mt * 16 + mi, a.M - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + (int64_t)m * a.ldx + packed_k0(j, g, KT)),
+                                         (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u;
+
+  stage(0, 0);
+  for (int ks = 0; ks < KS; ++ks) {
+    __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0): this wave's pieces of step ks have landed
+    __syncthreads();                           // ... everyone's have, and everyone finished reading buffer (ks+1)&1
+    if (ks + 1 < KS) stage(ks + 1, (ks + 1) & 1);
+    const unsigned b0 = lds0 + (unsigned)((ks & 1) * 32768);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (2 * ks + kk >= KT) break;
+      u32x4 wv[4], xv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wv[t] = lds_read_b128(b0 + (unsigned)(((wn * 4 + t) * 2 + kk) * 1024));
+        xv[t] = lds_read_b128(b0 + (unsigned)((16 + (wm * 4 + t) * 2 + kk) * 1024));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[tn]),
+                                                                *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
+    }
+  }
+
+  // epilogue identical to the direct variant: lane holds D[n = tile*16 + g*4 + j][m = tile*16 + mi]
+  const int n_tile0 = n_blk0 + wn * 4, m0 = m_blk0 + wm * 64;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + tm * 16 + mi;
+    if (m >= a.M) continue;
+    if (EPI == EPI_SILU) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int nt_gate = n_tile0 + tp * 2;
+        if (nt_gate >= NT) continue;
+        const int n = (nt_gate >> 1) * 16 + g * 4;
+        bf16_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gate = rbf(silu_f(rbf(acc[tp * 2][tm][j])));
+          float up = rbf(acc[tp * 2 + 1][tm][j]);
+          o[j] = f2bf(gate * up);
+        }
+        *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        if (n_tile0 + tn >= NT) continue;
+        const int n = (n_tile0 + tn) * 16 + g * 4;
+        bf16_t o[4];
+        if (EPI == EPI_RESIDUAL) {
+          uint2 rv = *reinterpret_cast<const uint2*>(a.res + (int64_t)m * a.ldr + n);
+          const bf16_t* re = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(re[j]) + rbf(acc[tn][tm][j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[tn][tm][j]);
+        }
+        *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
+      }
+    }
+  }
+}
+
+int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct) {
   FMI_REQUIRE(a.norm_w == nullptr, "linear_tiled: fused norm not supported (use rmsnorm_rows)");
   FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0 && a.ldo % 4 == 0, "linear_tiled: bad shape");
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_tiled: SwiGLU needs N %% 32");
   dim3 grid(cdiv(a.N / 16, 8), cdiv(a.M, 128)), block(256);
+  static const bool env_direct = []() { const char* e = getenv("FMI_GEMM"); return e && e[0] == 'd'; }();  // A/B switch
+  if (!env_direct && !force_direct) {
+    constexpr int smem = 2 * 32768;
+    static const hipError_t at0 = hipFuncSetAttribute((const void*)linear_tiled_lds_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t at1 = hipFuncSetAttribute((const void*)linear_tiled_lds_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t at2 = hipFuncSetAttribute((const void*)linear_tiled_lds_kernel<EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    FMI_CHECK_HIP(at0); FMI_CHECK_HIP(at1); FMI_CHECK_HIP(at2);
+    if (a.epi == EPI_STORE) hipLaunchKernelGGL(linear_tiled_lds_kernel<EPI_STORE>, grid, block, smem, s, a);
+    else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL(linear_tiled_lds_kernel<EPI_RESIDUAL>, grid, block, smem, s, a);
+    else hipLaunchKernelGGL(linear_tiled_lds_kernel<EPI_SILU>, grid, block, smem, s, a);
+    FMI_CHECK_HIP(hipGetLastError());
+    return FMI_OK;
+  }
   if (a.epi == EPI_STORE) hipLaunchKernelGGL(linear_tiled_kernel<EPI_STORE>, grid, block, 0, s, a);
   else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL(linear_tiled_kernel<EPI_RESIDUAL>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(linear_tiled_kernel<EPI_SILU>, grid, block, 0, s, a);

@@ -105,6 +105,24 @@ def test_skinny_linear_row_result_is_independent_of_the_batch_size(lib, N, K, ep
         assert torch.equal(one[0], big[r]), r
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1600, 6144, 2560, 0), (1600, 2560, 4096, 1), (777, 19456, 2560, 2),
+                                        (130, 2560, 9728, 1), (5, 192, 256, 0), (300, 320, 96, 2), (129, 4112, 2080, 0)])
+def test_lds_staged_prefill_gemm_equals_the_direct_variant(lib, M, N, K, epi):
+    """The prefill GEMM stages its operands through LDS (DMA, double-buffered); the earlier variant feeds the
+    MFMAs straight from L2.  Same MFMA order per output element -> identical bits, at the S2-Pro shapes (8 x 200
+    prompt rows), ragged M / N tails and an odd number of k-tiles; and both match the oracle."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    res = torch.randn(M, N, generator=g).bfloat16() if epi == 1 else None
+    staged = _linear(lib, x, w, None, res, M, N, K, epi, 2)
+    direct = _linear(lib, x, w, None, res, M, N, K, epi, 5)
+    assert torch.equal(staged, direct), float((staged.float() - direct.float()).abs().max())
+    if M <= 300:
+        ok, mx, nbad = bf16_close(staged, _linear_oracle(x, w, None, res, epi), scale=res)
+        assert ok, (mx, nbad)
+
+
 def _sample(lib, logits, ids, samp, frame, draw, prev, sem):
     from fish_speech_amd._lib import SamplingC, check
 
