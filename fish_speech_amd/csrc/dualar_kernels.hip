@@ -1133,6 +1133,21 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
   uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
   const float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
 
+  // Requested up front (none of it depends on this step's projections): the cached key rows this lane scores,
+  // the cached value elements it accumulates, and the first query head of this wave -- the kernel is a chain of
+  // memory round trips otherwise.
+  const int CH = D / 4;                      // dims per chunk lane (32 for D = 128)
+  const int kt = lane >> 2, kcn = lane & 3;  // lane = (key, chunk)
+  uint4 kpre[4];
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4)
+    if (kt < pos && j4 * 8 < CH) kpre[j4] = *reinterpret_cast<const uint4*>(kc + (int64_t)kt * D + kcn * CH + j4 * 8);
+  uint32_t vpre[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < pos) vpre[t] = *reinterpret_cast<const uint32_t*>(vc + (int64_t)t * D + 2 * p);
+  uint32_t qraw0 = (wave < G) ? *reinterpret_cast<const uint32_t*>(src + (kvh * G + wave) * D + 2 * p) : 0u;
+
   if (wave == 0) {  // key head: norm + rope -> cache + LDS
     uint32_t raw = *reinterpret_cast<const uint32_t*>(src + (H + kvh) * D + 2 * p);
     float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
@@ -1161,11 +1176,9 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
   __syncthreads();
 
   const float scale = (float)(1.0 / sqrt((double)D));
-  const int CH = D / 4;               // dims per chunk lane (32 for D = 128)
-  const int kt = lane >> 2, kcn = lane & 3;  // lane = (key, chunk)
   for (int gq = wave; gq < G; gq += 4) {
     const int h = kvh * G + gq;
-    uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+    uint32_t raw = (gq == wave) ? qraw0 : *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
     float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
     float y0 = x0, y1 = x1;
     if (a.qnw) {
@@ -1187,13 +1200,13 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
       if (kt == pos) {
         for (int j = 0; j < CH; ++j) d += s_q[wave][kcn * CH + j] * s_k[kcn * CH + j];
       } else {
-        const bf16_t* kr = kc + (int64_t)kt * D + kcn * CH;
-        for (int j = 0; j < CH; j += 8) {
-          uint4 kv8 = *reinterpret_cast<const uint4*>(kr + j);
-          const bf16_t* ke = reinterpret_cast<const bf16_t*>(&kv8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) d += s_q[wave][kcn * CH + j + e] * bf2f(ke[e]);
-        }
+        for (int j4 = 0; j4 < 4; ++j4)
+          if (j4 * 8 < CH) {
+            const bf16_t* ke = reinterpret_cast<const bf16_t*>(&kpre[j4]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += s_q[wave][kcn * CH + j4 * 8 + e] * bf2f(ke[e]);
+          }
       }
     }
     d = group_allsum<4>(d);
@@ -1221,7 +1234,7 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
           v0 = s_v[2 * p];
           v1 = s_v[2 * p + 1];
         } else {
-          const uint32_t vr = *reinterpret_cast<const uint32_t*>(vc + (int64_t)t * D + 2 * p);
+          const uint32_t vr = vpre[t];
           v0 = bf2f((bf16_t)(vr & 0xffff));
           v1 = bf2f((bf16_t)(vr >> 16));
         }
