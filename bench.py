@@ -29,7 +29,7 @@ import torch  # noqa: E402
 # HBM bytes fetched per decode frame at batch 8, from the separate rocprofv3 --pmc FETCH_SIZE pass
 # (profiles/r01_pmc_fetch_decode.txt; KiB x 1024 x 2 = the gfx950 correction of MI355X_MICROARCH.md).
 # PMC counters cannot be collected inside a timed run, so the figure is carried here with its provenance.
-PMC_FETCH_BYTES_PER_FRAME = 16.125e9
+PMC_FETCH_BYTES_PER_FRAME = 15.94e9
 
 FRAME_LEN = 2048          # samples per frame (modded_dac.py:833,861)
 SAMPLE_RATE = 44100
