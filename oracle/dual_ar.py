@@ -227,8 +227,36 @@ def slow_attention(q, k, v, mask, math_backend: bool):
 # ----------------------------------------------------------------------------- model
 
 
+def quantize_int8_per_channel(w: torch.Tensor):
+    """tools/llama/quantize.py:21-56 `dynamically_quantize_per_channel(w.float(), -128, 127, torch.int8)` as the
+    weight-only int8 handler calls it (quantize.py:190-200): symmetric per-output-row scale = max|row| / 127.5
+    (clamped to fp32 eps), round-to-nearest-even, clamp to [-128, 127].  Returns (int8 weight, scales in w.dtype)."""
+    x = w.float()
+    eps = torch.finfo(torch.float32).eps
+    lo, hi = torch.aminmax(x, dim=1)
+    amax = torch.max(-torch.min(lo, torch.zeros_like(lo)), torch.max(hi, torch.zeros_like(hi)))
+    scales = torch.clamp(amax / (float(127 - (-128)) / 2), min=eps)
+    q = torch.clamp(torch.round(x / scales.unsqueeze(-1)), -128, 127).to(torch.int8)
+    return q, scales.to(w.dtype)
+
+
+def quantize_state_int8(cfg: "DualARConfig", state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """What WeightOnlyInt8QuantHandler.create_quantized_state_dict (quantize.py:186-202) makes of a checkpoint:
+    every nn.Linear (wqkv, wo, w1, w2, w3 of the slow and fast layers, fast_output) becomes int8 `weight` +
+    `scales`; embeddings (hence the tied LM head) and norms stay as they are."""
+    out = dict(state)
+    for k, v in state.items():
+        if v.dim() == 2 and k.endswith(".weight") and "embeddings" not in k:
+            q, sc = quantize_int8_per_channel(v)
+            out[k] = q
+            out[k[: -len("weight")] + "scales"] = sc
+    return out
+
+
 class DualAROracle:
-    """Functional restatement of DualARTransformer's generate-time surface (llama.py:660-828)."""
+    """Functional restatement of DualARTransformer's generate-time surface (llama.py:660-828).
+    A state dict quantised by `quantize_state_int8` runs with WeightOnlyInt8Linear's arithmetic
+    (quantize.py:228-229: `F.linear(input, weight.to(input.dtype)) * scales`)."""
 
     def __init__(self, cfg: DualARConfig, state: Dict[str, torch.Tensor]):
         self.cfg = cfg
@@ -267,11 +295,17 @@ class DualAROracle:
             x = torch.where(is_sem.unsqueeze(-1).expand_as(x), x / math.sqrt(cfg.num_codebooks + 1), x)
         return x
 
+    def _lin(self, x: torch.Tensor, name: str) -> torch.Tensor:
+        w = self.w[name + ".weight"]
+        if w.dtype == torch.int8:
+            return F.linear(x, w.to(dtype=x.dtype)) * self.w[name + ".scales"]
+        return F.linear(x, w)
+
     def _block(self, prefix, x, tab, mask, pos, kv, n_head, n_kv, hd, qk_norm, slow, math_backend):
         w, eps = self.w, self.cfg.norm_eps
         B, S, _ = x.shape
         h_in = rms_norm(x, w[f"{prefix}.attention_norm.weight"], eps)
-        qkv = F.linear(h_in, w[f"{prefix}.attention.wqkv.weight"])
+        qkv = self._lin(h_in, f"{prefix}.attention.wqkv")
         q, k, v = qkv.split([n_head * hd, n_kv * hd, n_kv * hd], dim=-1)
         q = q.view(B, S, n_head, hd)
         k = k.view(B, S, n_kv, hd)
@@ -290,11 +324,10 @@ class DualAROracle:
         vv = vc.repeat_interleave(rep, dim=1)
         y = slow_attention(q, kk, vv, mask, math_backend) if slow else fast_attention(q, kk, vv, mask)
         y = y.transpose(1, 2).contiguous().view(B, S, n_head * hd)
-        h = x + F.linear(y, w[f"{prefix}.attention.wo.weight"])
+        h = x + self._lin(y, f"{prefix}.attention.wo")
         f_in = rms_norm(h, w[f"{prefix}.ffn_norm.weight"], eps)
-        ff = F.linear(F.silu(F.linear(f_in, w[f"{prefix}.feed_forward.w1.weight"]))
-                      * F.linear(f_in, w[f"{prefix}.feed_forward.w3.weight"]),
-                      w[f"{prefix}.feed_forward.w2.weight"])
+        ff = self._lin(F.silu(self._lin(f_in, f"{prefix}.feed_forward.w1")) * self._lin(f_in, f"{prefix}.feed_forward.w3"),
+                       f"{prefix}.feed_forward.w2")
         return h + ff
 
     # llama.py:390-466 + 819-828
@@ -329,7 +362,7 @@ class DualAROracle:
                             cfg.fast_n_local_heads, cfg.fast_head_dim, cfg.fast_attention_qk_norm,
                             False, False)
         out = rms_norm(x, self.w["fast_norm.weight"], cfg.norm_eps)
-        return F.linear(out, self.w["fast_output.weight"])
+        return self._lin(out, "fast_output")
 
     def fast_embeddings(self, a: torch.Tensor) -> torch.Tensor:
         return F.embedding(a, self.w["fast_embeddings.weight"])

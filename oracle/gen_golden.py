@@ -29,7 +29,7 @@ DUALAR_CASES = {
 }
 
 
-def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None, trace=None):
+def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None, trace=None, int8=False):
     """Run the reference's generate(); optionally record, per frame, what its own functions saw:
     the slow logits + hidden state (forward_generate) and every fast logits row (sample())."""
     add_reference_to_path()
@@ -37,6 +37,21 @@ def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None, trace=None):
     from fish_speech.models.text2semantic import llama as RL
 
     ref = build_reference_dual_ar(cfg, state)
+    if int8:  # the reference's own weight-only int8 path (tools/llama/quantize.py:186-229, llama.py:529-534)
+        from tools.llama.quantize import WeightOnlyInt8QuantHandler
+
+        handler = WeightOnlyInt8QuantHandler(ref)
+        qstate = handler.create_quantized_state_dict()
+        ref = handler.convert_for_runtime()
+        ref.load_state_dict(qstate, assign=True)
+        mine = O.quantize_state_int8(cfg, state)   # the restated quantizer must produce the very same checkpoint
+        for k, v in mine.items():
+            if v.dtype == torch.int8 or k.endswith(".scales"):
+                assert torch.equal(v, qstate[k]), k
+        n_q = sum(1 for v in qstate.values() if v.dtype == torch.int8)
+        assert n_q == 5 * (cfg.n_layer + cfg.n_fast_layer) + 1, n_q
+        ref.tokenizer = build_reference_dual_ar.__globals__["FakeTokenizer"](cfg.im_end_id)
+        ref._cache_setup_done = False
     orig_rand, orig_dec, orig_sample = torch.rand_like, RI.decode_one_token_ar, RI.sample
     orig_fg = RL.DualARTransformer.forward_generate
     calls = {"n": 0}
@@ -100,14 +115,19 @@ def live_ids(cfg):
     return torch.tensor(sorted(ids))
 
 
-def gen_dualar():
-    for name, (kw, sseed, gain, T, nsem, pseed, max_new) in DUALAR_CASES.items():
+def gen_dualar(only_int8=False):
+    cases = dict(DUALAR_CASES)
+    cases["tiny_int8"] = cases["tiny"]   # same weights, quantised by the reference's WeightOnlyInt8QuantHandler
+    for name, (kw, sseed, gain, T, nsem, pseed, max_new) in cases.items():
+        int8 = name.endswith("_int8")
+        if only_int8 and not int8:
+            continue
         cfg = O.DualARConfig(**kw)
         prompt = O.make_prompt(cfg, T, seed=pseed, n_semantic=nsem)
         state = O.make_synthetic_state(cfg, seed=sseed, head_gain=gain)
         tr = {}
-        greedy = _ref_generate(cfg, state, prompt, max_new, 1, O.FmiUniform(seed=1234, stream=0), trace=tr)
-        sampled = _ref_generate(cfg, state, prompt, max_new, 30, O.FmiUniform(seed=1234, stream=0))
+        greedy = _ref_generate(cfg, state, prompt, max_new, 1, O.FmiUniform(seed=1234, stream=0), trace=tr, int8=int8)
+        sampled = _ref_generate(cfg, state, prompt, max_new, 30, O.FmiUniform(seed=1234, stream=0), int8=int8)
         ids = live_ids(cfg)
         slow = torch.stack(tr["slow_logits"])[:, ids]
         hidden = torch.stack(tr["hidden"])
@@ -128,6 +148,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["dualar", "dac"]
     if "dualar" in which:
         gen_dualar()
+    if "int8" in which:
+        gen_dualar(only_int8=True)
     if "dac" in which:
         try:
             from .gen_golden_dac import gen_dac

@@ -78,3 +78,25 @@ def test_oracle_bit_exact_vs_reference_fp32_and_bf16():
         ref = _ref_generate(cfg, st, prompt, 10, 30, O.FmiUniform(99))
         got = O.generate(O.DualAROracle(cfg, st), prompt, 10, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(99))
         assert torch.equal(ref, got.long())
+
+
+def test_int8_weight_only_oracle_vs_reference_golden():
+    """§8f #2 groundwork: the reference's weight-only int8 path (tools/llama/quantize.py:186-229 -- per-row
+    symmetric quantisation, `F.linear(x, w.to(bf16)) * scales`) restated in the oracle, against the fixture the
+    unmodified reference wrote after quantising the tiny model with its own handler
+    (oracle/gen_golden.py asserts the restated quantiser reproduces that checkpoint bit for bit)."""
+    from tests.helpers import check_teacher_forced, oracle_step_fn
+
+    cfg, state, z = load_dualar_case("tiny_int8")
+    q = O.quantize_state_int8(cfg, state)
+    n_int8 = [k for k, v in q.items() if v.dtype == torch.int8]
+    assert len(n_int8) == 5 * (cfg.n_layer + cfg.n_fast_layer) + 1 and "embeddings.weight" not in n_int8
+    for k in n_int8:   # per-row grid with s = max|row| / 127.5: |w - q*s| <= s/2, up to s for the clipped row maximum
+        # (127.5 rounds to 128, clamps to 127), plus 127 * 2^-9 * s from the stored scale being bf16
+        w, s = state[k].float(), q[k[:-6] + "scales"].float()
+        assert int(q[k].abs().max()) <= 128 and bool(((w - q[k].float() * s[:, None]).abs() <= 1.3 * s[:, None] + 1e-6).all())
+    st = check_teacher_forced(oracle_step_fn(cfg, q, int(z["uniform_seed"])), cfg, z)
+    assert st["frames"] == z["greedy"].shape[1] - z["prompt"].shape[1]
+    assert st["exact"] >= 0.9 * st["decisions"]
+    _, _, zb = load_dualar_case("tiny")       # quantisation is visible: the traces differ from the bf16 model's
+    assert not np.array_equal(z["slow_logits_live"], zb["slow_logits_live"])
