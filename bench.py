@@ -65,6 +65,22 @@ def synthetic_state_on_device(cfg, device, seed=0):
     return st
 
 
+def quantize_state_int8_on_device(state):
+    """WeightOnlyInt8QuantHandler.create_quantized_state_dict (tools/llama/quantize.py:186-202) on the GPU tensors:
+    every 2-D non-embedding weight -> int8 + per-row bf16 scales (max|row| / 127.5)."""
+    out = {}
+    for k, v in state.items():
+        if v.dim() == 2 and k.endswith(".weight") and "embeddings" not in k:
+            x = v.float()
+            amax = x.abs().amax(dim=1)
+            scales = torch.clamp(amax / 127.5, min=torch.finfo(torch.float32).eps)
+            out[k] = torch.clamp(torch.round(x / scales[:, None]), -128, 127).to(torch.int8)
+            out[k[: -len("weight")] + "scales"] = scales.to(torch.bfloat16)
+        else:
+            out[k] = v
+    return out
+
+
 def make_prompts(cfg, n, base_seed):
     ps = []
     for i in range(n):
@@ -176,6 +192,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--int8", action="store_true",
+                    help="weight-only int8 checkpoint of the same model (NOT the headline number: reduced precision)")
     ap.add_argument("--no-codec", action="store_true", help="debug: Dual-AR only (INVALID as a result)")
     ap.add_argument("--frames", type=int, default=215, help="debug: fewer frames (INVALID as a result)")
     args = ap.parse_args()
@@ -203,11 +221,12 @@ def main():
 
     globals()["N_FRAMES"] = args.frames
     cfg = s2_pro_config()
+    cfg.weight_int8 = bool(args.int8)
     model = MiDualAR(cfg, device=device, im_end_id=cfg.im_end_id)
     state = None
     if rank == 0:
         state = synthetic_state_on_device(cfg, device)
-        model.load_state_dict(state)
+        model.load_state_dict(quantize_state_int8_on_device(state) if args.int8 else state)
     if world > 1:  # the only collective of the path: one broadcast of the packed weight arena (xGMI)
         from fish_speech_amd.dist import broadcast_arena
 
@@ -278,7 +297,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": "bf16 activations, int8 weights (NOT the headline configuration)" if args.int8 else "bf16",
         "data": "synthetic (random-init S2-Pro-shaped weights, random 200-token prompts, EOS ignored, 215 frames)",
         "config": {"workload": "configs[2]: S2-Pro 4B batch=8, 200-token prompts -> 10 s audio, hipGraph inner-AR loop",
                    "batch_per_gpu": BATCH, "prompt_tokens": PROMPT_T, "frames": N_FRAMES, "parallelism": f"utterance-sharded x{world}",

@@ -22,7 +22,8 @@ class DualARConfigC(C.Structure):
         "fast_intermediate_size", "codebook_size", "num_codebooks", "semantic_begin_id",
         "semantic_end_id", "im_end_id", "max_seq_len", "attention_qk_norm", "fast_attention_qk_norm",
         "scale_codebook_embeddings", "norm_fastlayer_input")] + [("rope_base", C.c_float),
-                                                                 ("norm_eps", C.c_float)]
+                                                                 ("norm_eps", C.c_float),
+                                                                 ("weight_int8", C.c_int32)]
 
 
 class SamplingC(C.Structure):
@@ -50,6 +51,7 @@ _SIGS = {
     "fmi_dualar_create": (C.c_int, [C.POINTER(DualARConfigC), _P, C.c_int64, C.POINTER(_P)]),
     "fmi_dualar_destroy": (None, [_P]),
     "fmi_dualar_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int64, _I, _P]),
+    "fmi_dualar_load_tensor_int8": (C.c_int, [_P, C.c_char_p, _P, _P, C.c_int64, C.c_int64, _I, _P]),
     "fmi_dualar_finalize_weights": (C.c_int, [_P, _P]),
     "fmi_dualar_weights_ready": (C.c_int, [_P]),
     "fmi_dualar_setup_caches": (C.c_int, [_P, _I, _I]),
@@ -70,6 +72,7 @@ _SIGS = {
     "fmi_dualar_set_graph": (C.c_int, [_P, _I]),
     "fmi_dualar_set_ignore_eos": (C.c_int, [_P, _I]),
     "fmi_dualar_last_decode_stats": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
+    "fmi_op_linear_int8": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_float, _I, _I, _P]),
     "fmi_op_linear_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, C.c_float, _I, _I, _P]),
     "fmi_op_sample": (C.c_int, [_P, _I, _I, _I, _P, C.POINTER(SamplingC), _I, _I, _P, _I, _I, _P, _P]),
     "fmi_dac_arena_bytes": (C.c_int64, [C.POINTER(DacConfigC)]),

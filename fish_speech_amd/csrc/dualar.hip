@@ -20,6 +20,10 @@ namespace {
 
 struct LayerW {
   bf16_t *wqkv, *wo, *w13, *w2, *attn_norm, *ffn_norm, *q_norm, *k_norm;
+  // weight-only int8 checkpoints (cfg.weight_int8): int8 tiles for the decode GEMV + per-row scales (packed order);
+  // the bf16 pointers above then hold the exactly dequantised weights for the prefill / M > 8 paths
+  int8_t *q_wqkv = nullptr, *q_wo = nullptr, *q_w13 = nullptr, *q_w2 = nullptr;
+  bf16_t *s_wqkv = nullptr, *s_wo = nullptr, *s_w13 = nullptr, *s_w2 = nullptr;
 };
 
 struct Dims {
@@ -43,6 +47,10 @@ struct fmi_dualar {
   std::vector<LayerW> L, FL;
   bf16_t *emb = nullptr, *cb_emb = nullptr, *norm = nullptr, *head_live = nullptr, *fast_emb = nullptr,
          *fast_norm = nullptr, *fast_out = nullptr, *rope = nullptr, *fast_rope = nullptr;
+  int8_t* q_fast_out = nullptr;   // int8 checkpoints: fast_output is an nn.Linear too
+  bf16_t* s_fast_out = nullptr;
+  void* staging2 = nullptr;       // dequantisation scratch of the int8 loader
+  size_t staging2_bytes = 0;
   int32_t* live_ids = nullptr;
   int n_live = 0, n_live_pad = 0;
   std::set<std::string> loaded;
@@ -125,6 +133,16 @@ int64_t layout(const fmi_dualar_config& c, fmi_dualar* h) {
     w.ffn_norm = (bf16_t*)take(d.dim, 2);
     w.q_norm = (bf16_t*)take(d.D, 2);
     w.k_norm = (bf16_t*)take(d.D, 2);
+    if (c.weight_int8) {
+      w.q_wqkv = (int8_t*)take((int64_t)d.qkv * d.dim, 1);
+      w.q_wo = (int8_t*)take((int64_t)d.dim * d.H * d.D, 1);
+      w.q_w13 = (int8_t*)take((int64_t)2 * d.ffn * d.dim, 1);
+      w.q_w2 = (int8_t*)take((int64_t)d.dim * d.ffn, 1);
+      w.s_wqkv = (bf16_t*)take(d.qkv, 2);
+      w.s_wo = (bf16_t*)take(d.dim, 2);
+      w.s_w13 = (bf16_t*)take((int64_t)2 * d.ffn, 2);
+      w.s_w2 = (bf16_t*)take(d.dim, 2);
+    }
     return w;
   };
   bf16_t* emb = (bf16_t*)take((int64_t)c.vocab_size * c.dim, 2);
@@ -137,6 +155,8 @@ int64_t layout(const fmi_dualar_config& c, fmi_dualar* h) {
   bf16_t* fout = (bf16_t*)take((int64_t)c.codebook_size * c.fast_dim, 2);
   bf16_t* rope = (bf16_t*)take((int64_t)c.max_seq_len * c.head_dim, 2);
   bf16_t* frope = (bf16_t*)take((int64_t)c.num_codebooks * c.fast_head_dim, 2);
+  int8_t* qfout = c.weight_int8 ? (int8_t*)take((int64_t)c.codebook_size * c.fast_dim, 1) : nullptr;
+  bf16_t* sfout = c.weight_int8 ? (bf16_t*)take(c.codebook_size, 2) : nullptr;
   std::vector<LayerW> L, FL;
   for (int i = 0; i < c.n_layer; ++i) L.push_back(layer(s));
   for (int i = 0; i < c.n_fast_layer; ++i) FL.push_back(layer(f));
@@ -144,6 +164,7 @@ int64_t layout(const fmi_dualar_config& c, fmi_dualar* h) {
     h->emb = emb; h->cb_emb = cb; h->norm = norm; h->head_live = head; h->live_ids = ids;
     h->fast_emb = femb; h->fast_norm = fnorm; h->fast_out = fout; h->rope = rope; h->fast_rope = frope;
     h->L = L; h->FL = FL; h->n_live = n_live; h->n_live_pad = n_live_pad;
+    h->q_fast_out = qfout; h->s_fast_out = sfout;
   }
   return off;
 }
@@ -214,10 +235,11 @@ int ensure_rows(fmi_dualar* h, int rows) {
 
 // out = linear(norm?(x)) for M rows; picks the skinny (fused norm) or tiled path.
 int linear(fmi_dualar* h, const bf16_t* x, int ldx, const bf16_t* wp, const bf16_t* norm_w, const bf16_t* res,
-           int ldr, bf16_t* out, int ldo, int M, int N, int K, int epi, hipStream_t s) {
+           int ldr, bf16_t* out, int ldo, int M, int N, int K, int epi, hipStream_t s, const int8_t* wq = nullptr,
+           const bf16_t* scale = nullptr) {
   LinearArgs a{};
   a.wp = wp; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = h->cfg.norm_eps; a.res = res; a.ldr = ldr;
-  a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epi = epi;
+  a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epi = epi; a.wq = wq; a.scale = scale;
   if (M <= 16) {
     h->launches += 1;
     return launch_linear_skinny(a, s);
@@ -238,7 +260,7 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
                const int32_t* row_pos, hipStream_t s) {
   const Dims& d = h->slow;
   Workspace& ws = h->ws;
-  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, rows, d.qkv, d.dim, EPI_STORE, s));
+  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, rows, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
   AttnArgs a{};
   a.qkv = ws.qkv; a.q = ws.q; a.out = ws.ao; a.kpool = h->kpool[layer]; a.vpool = h->vpool[layer];
   a.qnw = h->cfg.attention_qk_norm ? w.q_norm : nullptr;
@@ -254,9 +276,9 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
     FMI_CHECK(launch_attn(a, s));
     h->launches += 2;
   }
-  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s));
-  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s));
-  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.ffn, EPI_RESIDUAL, s));
+  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
+  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2));
   return FMI_OK;
 }
 
@@ -264,7 +286,7 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
                hipStream_t s, bool kv_only = false) {
   const Dims& d = h->fast;
   Workspace& ws = h->ws;
-  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s));
+  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
   FastAttnArgs a{};
   a.qkv = ws.qkv; a.out = ws.ao; a.kc = h->fkc[layer]; a.vc = h->fvc[layer];
   a.qnw = h->cfg.fast_attention_qk_norm ? w.q_norm : nullptr;
@@ -274,9 +296,9 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
   FMI_CHECK(launch_fast_attn(a, s));
   h->launches += 1;
   if (kv_only) return FMI_OK;  // only this layer's K/V at `pos` were needed
-  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s));
-  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s));
-  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s));
+  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
+  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2));
   return FMI_OK;
 }
 
@@ -316,7 +338,7 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   for (int cb = 1; cb < c.num_codebooks; ++cb) {
     for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, B, cb, row_slot, s));
     FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, B,
-                     c.codebook_size, c.fast_dim, EPI_STORE, s));
+                     c.codebook_size, c.fast_dim, EPI_STORE, s, h->q_fast_out, h->s_fast_out));
     if (h->trace) {
       FMI_CHECK_HIP(hipMemcpy2DAsync(h->ftrace + (int64_t)cb * c.codebook_size,
                                      (size_t)c.num_codebooks * c.codebook_size * 2, h->flogits,
@@ -457,7 +479,7 @@ void fmi_dualar_destroy(fmi_dualar* h) {
   for (auto p : h->fvc) hipFree(p);
   void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
                   h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
-                  h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging};
+                  h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging, h->staging2};
   for (void* p : ptrs)
     if (p) hipFree(p);
   hipEventDestroy(h->ev_in);
@@ -526,6 +548,74 @@ int fmi_dualar_load_tensor(fmi_dualar* h, const char* name_c, const void* src, i
   }
   FMI_CHECK(rc);
   if (!src_is_device) FMI_CHECK_HIP(hipStreamSynchronize(s));  // staging buffer is reused
+  h->loaded.insert(name);
+  return sync_out(h, stream);
+}
+
+int fmi_dualar_load_tensor_int8(fmi_dualar* h, const char* name_c, const void* weight_i8, const void* scales_bf16,
+                                int64_t rows, int64_t cols, int src_is_device, void* stream) {
+  FMI_REQUIRE(h && name_c && weight_i8 && scales_bf16, "null argument");
+  FMI_REQUIRE(h->cfg.weight_int8, "the handle was not created with weight_int8=1");
+  FMI_REQUIRE(cols % 64 == 0, "int8 linears need K %% 64 == 0 (got %lld)", (long long)cols);
+  const std::string name(name_c);
+  const fmi_dualar_config& c = h->cfg;
+  FMI_CHECK(sync_in(h, stream));
+  hipStream_t s = h->stream;
+  const int64_t n = rows * cols;
+  // device copies of the int8 weight and its scales, and the exact bf16 dequantisation (row-major scratch)
+  const size_t need = (size_t)n + (size_t)rows * 2 + 256;
+  FMI_CHECK(ensure_staging(h, need));
+  int8_t* dq = (int8_t*)h->staging;
+  bf16_t* dscale = (bf16_t*)((char*)h->staging + align_up(n, 256));
+  const hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  FMI_CHECK_HIP(hipMemcpyAsync(dq, weight_i8, (size_t)n, kind, s));
+  FMI_CHECK_HIP(hipMemcpyAsync(dscale, scales_bf16, (size_t)rows * 2, kind, s));
+  if (h->staging2_bytes < (size_t)n * 2) {
+    if (h->staging2) FMI_CHECK_HIP(hipFree(h->staging2));
+    h->staging2 = nullptr;
+    h->staging2_bytes = 0;
+    FMI_CHECK_HIP(hipMalloc(&h->staging2, (size_t)n * 2));
+    h->staging2_bytes = (size_t)n * 2;
+  }
+  bf16_t* deq = (bf16_t*)h->staging2;
+  FMI_CHECK(launch_dequant_int8(dq, deq, n, s));
+  auto expect = [&](int64_t r, int64_t cc) -> int {
+    if (rows != r || cols != cc)
+      return set_error(FMI_EINVAL, "%s: shape (%lld,%lld) != expected (%lld,%lld)", name.c_str(), (long long)rows,
+                       (long long)cols, (long long)r, (long long)cc);
+    return FMI_OK;
+  };
+  auto put = [&](bf16_t* wp, int8_t* wq, bf16_t* sc, int interleave) -> int {
+    FMI_CHECK(launch_pack_weight(deq, wp, (int)rows, (int)cols, interleave, s));
+    FMI_CHECK(launch_pack_weight_int8(dq, wq, (int)rows, (int)cols, interleave, s));
+    return launch_pack_scale(dscale, sc, (int)rows, interleave, s);
+  };
+  int rc;
+  if (name == "fast_output.weight") {
+    FMI_CHECK(expect(c.codebook_size, c.fast_dim));
+    rc = put(h->fast_out, h->q_fast_out, h->s_fast_out, 0);
+  } else {
+    const bool fastl = name.rfind("fast_layers.", 0) == 0;
+    const bool slowl = name.rfind("layers.", 0) == 0;
+    if (!fastl && !slowl) return set_error(FMI_EINVAL, "'%s' is not a quantised linear", name.c_str());
+    const size_t p0 = fastl ? 12 : 7;
+    const size_t dot = name.find('.', p0);
+    if (dot == std::string::npos) return set_error(FMI_EINVAL, "bad tensor name '%s'", name.c_str());
+    const int idx = atoi(name.substr(p0, dot - p0).c_str());
+    const std::string sub = name.substr(dot + 1);
+    const Dims& d = fastl ? h->fast : h->slow;
+    std::vector<LayerW>& LL = fastl ? h->FL : h->L;
+    if (idx < 0 || idx >= (int)LL.size()) return set_error(FMI_EINVAL, "layer index out of range in '%s'", name.c_str());
+    LayerW& w = LL[idx];
+    if (sub == "attention.wqkv.weight") { FMI_CHECK(expect(d.qkv, d.dim)); rc = put(w.wqkv, w.q_wqkv, w.s_wqkv, 0); }
+    else if (sub == "attention.wo.weight") { FMI_CHECK(expect(d.dim, d.H * d.D)); rc = put(w.wo, w.q_wo, w.s_wo, 0); }
+    else if (sub == "feed_forward.w1.weight") { FMI_CHECK(expect(d.ffn, d.dim)); rc = put(w.w13, w.q_w13, w.s_w13, 1); }
+    else if (sub == "feed_forward.w3.weight") { FMI_CHECK(expect(d.ffn, d.dim)); rc = put(w.w13, w.q_w13, w.s_w13, 2); }
+    else if (sub == "feed_forward.w2.weight") { FMI_CHECK(expect(d.dim, d.ffn)); rc = put(w.w2, w.q_w2, w.s_w2, 0); }
+    else return set_error(FMI_EINVAL, "'%s' is not a quantised linear", name.c_str());
+  }
+  FMI_CHECK(rc);
+  FMI_CHECK_HIP(hipStreamSynchronize(s));  // staging buffers are reused
   h->loaded.insert(name);
   return sync_out(h, stream);
 }
@@ -880,7 +970,7 @@ int fmi_dualar_forward_fast(fmi_dualar* h, int slot, const void* hidden_in_dev, 
   FMI_CHECK_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, 1, pos, h->ws.row_slot, s));
   FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, 1,
-                   c.codebook_size, c.fast_dim, EPI_STORE, s));
+                   c.codebook_size, c.fast_dim, EPI_STORE, s, h->q_fast_out, h->s_fast_out));
   FMI_CHECK_HIP(hipMemcpyAsync(logits_out_dev, h->flogits, (size_t)c.codebook_size * 2, hipMemcpyDeviceToDevice, s));
   return sync_out(h, stream);
 }
@@ -969,6 +1059,43 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
   hipStreamSynchronize(s);
   hipFree(packed);
   if (xn) hipFree(xn);
+  return rc;
+}
+
+int fmi_op_linear_int8(const void* x_dev, const void* w_i8_dev, const void* scales_dev, const void* norm_w_dev,
+                       const void* residual_dev, void* out_dev, int M, int N, int K, float eps, int epilogue,
+                       int stream_int8, void* stream) {
+  FMI_REQUIRE(x_dev && w_i8_dev && scales_dev && out_dev, "null argument");
+  FMI_REQUIRE(epilogue >= 0 && epilogue <= 2 && M >= 1 && M <= 16 && K % 64 == 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t *deq = nullptr, *packed = nullptr, *sc = nullptr;
+  int8_t* q = nullptr;
+  FMI_CHECK_HIP(hipMalloc((void**)&deq, (size_t)N * K * 2));
+  FMI_CHECK_HIP(hipMalloc((void**)&packed, (size_t)N * K * 2));
+  FMI_CHECK_HIP(hipMalloc((void**)&q, (size_t)N * K));
+  FMI_CHECK_HIP(hipMalloc((void**)&sc, (size_t)N * 2));
+  const int n_out = (epilogue == EPI_SILU) ? N / 2 : N;
+  int rc = launch_dequant_int8((const int8_t*)w_i8_dev, deq, (int64_t)N * K, s);
+  auto pack = [&](int64_t row0, int rows, int il) -> int {
+    FMI_CHECK(launch_pack_weight(deq + row0 * K, packed, rows, K, il, s));
+    FMI_CHECK(launch_pack_weight_int8((const int8_t*)w_i8_dev + row0 * K, q, rows, K, il, s));
+    return launch_pack_scale((const bf16_t*)scales_dev + row0, sc, rows, il, s);
+  };
+  if (rc == FMI_OK) {
+    if (epilogue == EPI_SILU) {
+      rc = pack(0, N / 2, 1);
+      if (rc == FMI_OK) rc = pack(N / 2, N / 2, 2);
+    } else {
+      rc = pack(0, N, 0);
+    }
+  }
+  LinearArgs a{};
+  a.wp = packed; a.x = (const bf16_t*)x_dev; a.ldx = K; a.norm_w = (const bf16_t*)norm_w_dev; a.eps = eps;
+  a.res = (const bf16_t*)residual_dev; a.ldr = n_out; a.out = (bf16_t*)out_dev; a.ldo = n_out; a.M = M; a.N = N;
+  a.K = K; a.epi = epilogue; a.scale = sc; a.wq = stream_int8 ? q : nullptr;
+  if (rc == FMI_OK) rc = launch_linear_skinny(a, s);
+  hipStreamSynchronize(s);
+  hipFree(deq); hipFree(packed); hipFree(q); hipFree(sc);
   return rc;
 }
 

@@ -33,6 +33,13 @@ struct SlotState {
 // serves both tiles.
 // interleave: 0 identity; 1/2 = w1/w3 halves of the SwiGLU pair, 16-row blocks alternating.
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int interleave, hipStream_t s);
+// int8 row-major (N,K) -> [N/16][K/64][64 lanes][2 tiles][8 int8]: the two k-tiles of a pair side by side, same k
+// permutation as the bf16 layout (one 16-byte load per lane per pair).  K must be a multiple of 64.
+int launch_pack_weight_int8(const int8_t* src, int8_t* dst, int N, int K, int interleave, hipStream_t s);
+// int8 row-major -> bf16 row-major (exact), for the bf16 copy the prefill / M > 8 paths use
+int launch_dequant_int8(const int8_t* src, bf16_t* dst, int64_t n, hipStream_t s);
+// scale vector into packed row order (interleave as launch_pack_weight)
+int launch_pack_scale(const bf16_t* src, bf16_t* dst, int N, int interleave, hipStream_t s);
 // gather `n` rows listed in ids_dev (int32 vocab ids, on device) then pack (live LM-head rows).
 int launch_pack_rows_gather(const bf16_t* src, const int32_t* ids_dev, bf16_t* dst, int n, int n_pad,
                             int K, hipStream_t s);
@@ -50,6 +57,11 @@ struct LinearArgs {
   int ldo;
   int M, N, K;             // N = packed rows (2*ffn for EPI_SILU)
   int epi;
+  // weight-only int8 checkpoints (tools/llama/quantize.py:204-229): out = bf16(bf16(acc) * scale[row]) before the
+  // epilogue.  `scale` is in PACKED row order (gate/up interleaved for SwiGLU); `wq` = the int8 tiles
+  // (launch_pack_weight_int8) streamed by the M <= 8 decode GEMV instead of `wp` -- half the bytes.
+  const bf16_t* scale;
+  const int8_t* wq;
 };
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s);  // M <= 16
 int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct = false);  // any M, no fused norm

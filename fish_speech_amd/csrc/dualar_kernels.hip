@@ -72,6 +72,57 @@ int launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int interle
   return FMI_OK;
 }
 
+__global__ void pack_weight_int8_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst, int N, int K,
+                                        int interleave) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 elements
+  int64_t total = (int64_t)N * K / 8;
+  if (idx >= total) return;
+  const int kc = (int)(idx % (K / 8)), n = (int)(idx / (K / 8));
+  int nd = n;
+  if (interleave == 1) nd = (n >> 4) * 32 + (n & 15);
+  if (interleave == 2) nd = (n >> 4) * 32 + 16 + (n & 15);
+  const int k = kc * 8, P = K >> 6;
+  const int p = k >> 6, kt = (k >> 5) & 1, g = (k >> 3) & 3;
+  const int t = g & 1, kg = kt * 2 + (g >> 1);                   // same chunk map as packed_index
+  const int64_t o = ((((int64_t)(nd >> 4) * P + p) * 64 + kg * 16 + (nd & 15)) * 2 + t) * 8;
+  *reinterpret_cast<uint2*>(dst + o) = *reinterpret_cast<const uint2*>(src + (int64_t)n * K + k);
+}
+
+int launch_pack_weight_int8(const int8_t* src, int8_t* dst, int N, int K, int interleave, hipStream_t s) {
+  FMI_REQUIRE(N % 16 == 0 && K % 64 == 0, "pack_weight_int8: N=%d must be a multiple of 16 and K=%d of 64", N, K);
+  int64_t total = (int64_t)N * K / 8;
+  hipLaunchKernelGGL(pack_weight_int8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, N, K,
+                     interleave);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+__global__ void dequant_int8_kernel(const int8_t* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = f2bf((float)src[i]);   // |v| <= 128: exact in bf16
+}
+
+int launch_dequant_int8(const int8_t* src, bf16_t* dst, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(dequant_int8_kernel, dim3(2048), dim3(256), 0, s, src, dst, n);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+__global__ void pack_scale_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int interleave) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int nd = n;
+  if (interleave == 1) nd = (n >> 4) * 32 + (n & 15);
+  if (interleave == 2) nd = (n >> 4) * 32 + 16 + (n & 15);
+  dst[nd] = src[n];
+}
+
+int launch_pack_scale(const bf16_t* src, bf16_t* dst, int N, int interleave, hipStream_t s) {
+  hipLaunchKernelGGL(pack_scale_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, src, dst, N, interleave);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
 __global__ void pack_rows_gather_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ ids,
                                         bf16_t* __restrict__ dst, int n, int n_pad, int K) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,9 +320,14 @@ __device__ inline float dpp_row_shl8(float v) {  // lane n of every 16-lane row 
 
 // UNR = k-tile pairs in flight per wave; TILES = 16-row weight tiles per work-group (SwiGLU: gate/up tiles
 // alternate, so TILES is even); PAIRX = the M <= 8 activation path.
-template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool PAIRX, bool NT = true>
+// Q8: the weights are the int8 tiles of a weight-only-int8 checkpoint (a.wq, launch_pack_weight_int8): one 16-byte
+// load per lane brings both k-tiles of a pair, converted to bf16 in registers (exact: |v| <= 128) right before the
+// same MFMAs -- the products, their order and hence the result bits equal the bf16 kernel on the dequantised
+// weights, at half the streamed bytes.  a.scale (any variant) applies the per-row scale of the int8 linear.
+template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool PAIRX, bool NT = true, bool Q8 = false>
 __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a) {
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
+  static_assert(!Q8 || PAIRX, "the int8 stream is the M <= 8 decode path");
   __shared__ float red[WAVES][TILES][256];
   __shared__ float s_rstd[16];
 
@@ -282,9 +338,11 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
   const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
 
   const int pbeg = (int)((int64_t)wave * P / WAVES), pend = (int)((int64_t)(wave + 1) * P / WAVES);
-  const u32x4* wrow[TILES];
+  const u32x4* wrow[TILES];  // bf16: [KT][64] u32x4 per tile row-block; int8: [P][64] u32x4 (a pair per entry)
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) wrow[t] = wp + ((int64_t)(tile0 + t) * KT) * 64 + lane;
+  for (int t = 0; t < TILES; ++t)
+    wrow[t] = Q8 ? reinterpret_cast<const u32x4*>(a.wq) + ((int64_t)(tile0 + t) * P) * 64 + lane
+                 : wp + ((int64_t)(tile0 + t) * KT) * 64 + lane;
 
   // the first chunk of weight tiles is issued BEFORE the RMSNorm prologue so that HBM latency overlaps
   // the row statistics
@@ -295,9 +353,24 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
-        wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u)) * 64);
-        wa[t][u][1] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u) + 1) * 64);
+        if (Q8) {
+          wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(p0 + u) * 64);
+        } else {
+          wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u)) * 64);
+          wa[t][u][1] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u) + 1) * 64);
+        }
       }
+  };
+  // int8 pair register (tile 0's 8 values | tile 1's 8 values) -> the two bf16 A operands
+  auto unpack_q8 = [](const u32x4& q, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const uint32_t w0 = q[d], w1 = q[2 + d];
+      lo[2 * d] = cvt_pk_bf16((float)(int8_t)(w0), (float)(int8_t)(w0 >> 8));
+      lo[2 * d + 1] = cvt_pk_bf16((float)(int8_t)(w0 >> 16), (float)(int8_t)(w0 >> 24));
+      hi[2 * d] = cvt_pk_bf16((float)(int8_t)(w1), (float)(int8_t)(w1 >> 8));
+      hi[2 * d + 1] = cvt_pk_bf16((float)(int8_t)(w1 >> 16), (float)(int8_t)(w1 >> 24));
+    }
   };
   if (nfull > 0) load_chunk(pbeg);
 
@@ -352,8 +425,10 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
-        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][u][0]), x0[u], acc0[t], 0, 0, 0);
-        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][u][1]), x1[u], acc1[t], 0, 0, 0);
+        u32x4 w0 = wa[t][u][0], w1 = wa[t][u][1];
+        if (Q8) unpack_q8(wa[t][u][0], w0, w1);
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), x0[u], acc0[t], 0, 0, 0);
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), x1[u], acc1[t], 0, 0, 0);
       }
   };
 
@@ -374,7 +449,14 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 w0 = wload<NT>(wrow[t] + (int64_t)(2 * p) * 64), w1 = wload<NT>(wrow[t] + (int64_t)(2 * p + 1) * 64);
+      u32x4 w0, w1;
+      if (Q8) {
+        const u32x4 q = wload<NT>(wrow[t] + (int64_t)p * 64);
+        unpack_q8(q, w0, w1);
+      } else {
+        w0 = wload<NT>(wrow[t] + (int64_t)(2 * p) * 64);
+        w1 = wload<NT>(wrow[t] + (int64_t)(2 * p + 1) * 64);
+      }
       acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), x0, acc0[t], 0, 0, 0);
       acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), x1, acc1[t], 0, 0, 0);
     }
@@ -384,7 +466,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc0[t][j] += PAIRX ? dpp_row_shl8(acc1[t][j]) : acc1[t][j];
-  if ((KT & 1) && wave == WAVES - 1) {  // unpaired last k-tile (plain k order), after the fold: same in both variants
+  if (!Q8 && (KT & 1) && wave == WAVES - 1) {  // unpaired last k-tile (plain k order), after the fold: same in both variants
     const int kt = KT - 1;
     const int row = b < a.M ? b : 0;
     uint4 xv = *reinterpret_cast<const uint4*>(a.x + (int64_t)row * a.ldx + kt * 32 + g * 8);
@@ -416,7 +498,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
         float sacc = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sacc += red[w][t][ridx];
-        v[t] = sacc;
+        v[t] = rbf(sacc);   // the linear's bf16 output ...
+        if (a.scale) v[t] = rbf(v[t] * bf2f(a.scale[(tile0 + t) * 16 + r]));  // ... times the int8 row scale
       }
       if (EPI == EPI_STORE) {
 #pragma unroll
@@ -425,14 +508,14 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           const int n = (tile0 + t) * 16 + r;
-          a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + rbf(v[t]));
+          a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + v[t]);
         }
       } else {  // SwiGLU: even tiles = gate rows, odd tiles = up rows (llama.py:987)
 #pragma unroll
         for (int t = 0; t < TILES; t += 2) {
           const int n = ((tile0 + t) >> 1) * 16 + r;
-          float gate = rbf(silu_f(rbf(v[t])));
-          float up = rbf(v[t + 1 < TILES ? t + 1 : t]);
+          float gate = rbf(silu_f(v[t]));
+          float up = v[t + 1 < TILES ? t + 1 : t];
           a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
         }
       }
@@ -450,10 +533,17 @@ static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
     if (pairx) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, false>), grid, block, 0, s, a);   \
   } while (0)
-  if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH(EPI_STORE, true); else FMI_LAUNCH(EPI_STORE, false); }
+#define FMI_LAUNCH_Q8(EPI_, NORM_) \
+  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true, true, true>), grid, block, 0, s, a)
+  if (a.wq && pairx && (a.K % 64) == 0) {   // weight-only int8 checkpoint: stream the int8 tiles
+    if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH_Q8(EPI_STORE, true); else FMI_LAUNCH_Q8(EPI_STORE, false); }
+    else if (a.epi == EPI_RESIDUAL) { if (norm) FMI_LAUNCH_Q8(EPI_RESIDUAL, true); else FMI_LAUNCH_Q8(EPI_RESIDUAL, false); }
+    else if constexpr (TILES % 2 == 0) { if (norm) FMI_LAUNCH_Q8(EPI_SILU, true); else FMI_LAUNCH_Q8(EPI_SILU, false); }
+  } else if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH(EPI_STORE, true); else FMI_LAUNCH(EPI_STORE, false); }
   else if (a.epi == EPI_RESIDUAL) { if (norm) FMI_LAUNCH(EPI_RESIDUAL, true); else FMI_LAUNCH(EPI_RESIDUAL, false); }
   else if constexpr (TILES % 2 == 0) { if (norm) FMI_LAUNCH(EPI_SILU, true); else FMI_LAUNCH(EPI_SILU, false); }
 #undef FMI_LAUNCH
+#undef FMI_LAUNCH_Q8
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -474,6 +564,16 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_skinny: SwiGLU needs N %% 32");
   const int KT = a.K / 32;
   const int ntile = a.N / 16;
+  if (a.wq && a.M <= 8 && a.K % 64 == 0 && KT >= 32) {
+    // int8 stream: a pair is 1 KiB instead of 2, so twice the pairs are kept in flight -- what bounds the kernel
+    // is cache lines in flight per CU, and with the bf16 depth the int8 stream was no faster than bf16
+    if (a.epi == EPI_SILU) return launch_skinny_t<8, 2, 2>(a, s);
+    if (a.norm_w) {
+      if (ntile % 2 == 0 && ntile > 320) return launch_skinny_t<8, 2, 2>(a, s);
+      return launch_skinny_t<8, 4, 1>(a, s);
+    }
+    return launch_skinny_t<8, 4, 1>(a, s);
+  }
   if (KT < 32) {  // tiny test models
     if (a.epi == EPI_SILU || ntile % 2 == 0) return launch_skinny_t<4, 1, 2>(a, s);
     return launch_skinny_t<4, 1, 1>(a, s);
@@ -491,6 +591,13 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
 // tiled linear (any M; prefill): 128x128 block, 4 waves (2x2), each 64x64 = 4x4 MFMA tiles.
 // Operands go straight from global/L2 into fragments (weights are already fragment-ordered).
 // =====================================================================================
+
+// bf16 output of a linear, times the per-row scale of a weight-only-int8 checkpoint (packed row order) if present
+__device__ inline float lin_out(float acc, const bf16_t* scale, int packed_row) {
+  float o = rbf(acc);
+  if (scale) o = rbf(o * bf2f(scale[packed_row]));
+  return o;
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void linear_tiled_kernel(LinearArgs a) {
@@ -548,8 +655,8 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(LinearArgs a) {
         bf16_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float gate = rbf(silu_f(rbf(acc[tp * 2][tm][j])));
-          float up = rbf(acc[tp * 2 + 1][tm][j]);
+          float gate = rbf(silu_f(lin_out(acc[tp * 2][tm][j], a.scale, nt_gate * 16 + g * 4 + j)));
+          float up = lin_out(acc[tp * 2 + 1][tm][j], a.scale, (nt_gate + 1) * 16 + g * 4 + j);
           o[j] = f2bf(gate * up);
         }
         *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
@@ -564,10 +671,10 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(LinearArgs a) {
           uint2 rv = *reinterpret_cast<const uint2*>(a.res + (int64_t)m * a.ldr + n);
           const bf16_t* re = reinterpret_cast<const bf16_t*>(&rv);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(re[j]) + rbf(acc[tn][tm][j]));
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(re[j]) + lin_out(acc[tn][tm][j], a.scale, n + j));
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[tn][tm][j]);
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(lin_out(acc[tn][tm][j], a.scale, n + j));
         }
         *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
       }
@@ -666,8 +773,8 @@ __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
         bf16_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float gate = rbf(silu_f(rbf(acc[tp * 2][tm][j])));
-          float up = rbf(acc[tp * 2 + 1][tm][j]);
+          float gate = rbf(silu_f(lin_out(acc[tp * 2][tm][j], a.scale, nt_gate * 16 + g * 4 + j)));
+          float up = lin_out(acc[tp * 2 + 1][tm][j], a.scale, (nt_gate + 1) * 16 + g * 4 + j);
           o[j] = f2bf(gate * up);
         }
         *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
@@ -682,10 +789,10 @@ __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
           uint2 rv = *reinterpret_cast<const uint2*>(a.res + (int64_t)m * a.ldr + n);
           const bf16_t* re = reinterpret_cast<const bf16_t*>(&rv);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(re[j]) + rbf(acc[tn][tm][j]));
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(re[j]) + lin_out(acc[tn][tm][j], a.scale, n + j));
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[tn][tm][j]);
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(lin_out(acc[tn][tm][j], a.scale, n + j));
         }
         *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
       }

@@ -58,6 +58,7 @@ class DualARConfig:
     fast_head_dim: Optional[int] = None
     fast_intermediate_size: Optional[int] = None
     fast_attention_qk_norm: Optional[bool] = None
+    weight_int8: bool = False     # weight-only int8 checkpoint (tools/llama/quantize.py); set by load_state_dict's caller
 
     def __post_init__(self):  # defaults follow llama.py:165-193
         self.fast_dim = self.fast_dim or self.dim
@@ -251,12 +252,28 @@ class MiDualAR:
             pre = k[: -len("wq.weight")]
             state[pre + "wqkv.weight"] = torch.cat([state.pop(pre + "wq.weight"), state.pop(pre + "wk.weight"),
                                                     state.pop(pre + "wv.weight")])
+            if pre + "wq.scales" in state:
+                state[pre + "wqkv.scales"] = torch.cat([state.pop(pre + "wq.scales"), state.pop(pre + "wk.scales"),
+                                                        state.pop(pre + "wv.scales")])
         cfg = self.config
         state.setdefault("freqs_cis", _rope_table(cfg.max_seq_len, cfg.head_dim, cfg.rope_base))
         state.setdefault("fast_freqs_cis", _rope_table(cfg.num_codebooks, cfg.fast_head_dim, cfg.rope_base))
         s = self._stream()
+        quantised = {k[: -len("scales")] + "weight" for k in state if k.endswith(".scales")}
+        if quantised and not cfg.weight_int8:
+            raise ValueError("this state dict is a weight-only int8 checkpoint: build the model with "
+                             "DualARConfig(weight_int8=True) (from_pretrained does it for '*int8*' paths)")
+        for name in sorted(quantised):   # int8 weight + per-row scales (WeightOnlyInt8QuantHandler, quantize.py:186-202)
+            w = state[name].detach().to(self.device).contiguous()
+            sc = state[name[: -len("weight")] + "scales"].detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+            if w.dtype != torch.int8:
+                raise ValueError(f"{name}: expected an int8 weight next to its .scales, got {w.dtype}")
+            rc = self.lib.fmi_dualar_load_tensor_int8(self._h, name.encode(), C.c_void_p(w.data_ptr()),
+                                                      C.c_void_p(sc.data_ptr()), w.shape[0], w.shape[1], 1, s)
+            check(rc)
+            torch.cuda.current_stream(self.device).synchronize()
         for name, t in state.items():
-            if name in ("causal_mask",):
+            if name in ("causal_mask",) or name in quantised or name.endswith(".scales"):
                 continue
             t = t.detach()
             if t.dtype != torch.bfloat16:
@@ -306,6 +323,10 @@ class MiDualAR:
             cfg = DualARConfig.from_any(data, im_end)
         if max_length is not None:
             cfg.max_seq_len = max_length
+        if "int8" in str(path):     # llama.py:529-534
+            cfg.weight_int8 = True
+        if "int4" in str(path):     # llama.py:536-544
+            raise _lib.FishmiError("int4 checkpoints are not supported by fish_speech_amd")
         model = cls(cfg, device=device, tokenizer=tokenizer)
         index = os.path.join(path, "model.safetensors.index.json")
         weights: Dict[str, torch.Tensor] = {}

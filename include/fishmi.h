@@ -44,6 +44,9 @@ typedef struct fmi_dualar_config {
   int32_t attention_qk_norm, fast_attention_qk_norm;
   int32_t scale_codebook_embeddings, norm_fastlayer_input;
   float rope_base, norm_eps;
+  int32_t weight_int8; /* 1: weight-only int8 checkpoint (tools/llama/quantize.py:186-229): every nn.Linear carries
+                          an int8 weight + per-row bf16 scales; the arena then also holds the int8 tiles the
+                          decode GEMV streams (half the bytes) */
 } fmi_dualar_config;
 
 typedef struct fmi_dualar fmi_dualar;
@@ -64,6 +67,12 @@ void fmi_dualar_destroy(fmi_dualar* h);
  * load_state_dict in BaseTransformer.from_pretrained (llama.py:480-594). */
 int fmi_dualar_load_tensor(fmi_dualar* h, const char* name, const void* src, int64_t rows,
                            int64_t cols, int src_is_device, void* stream);
+/* Load one quantised linear of a weight-only-int8 checkpoint: `weight_i8` (rows, cols) int8 row-major and its
+ * `scales_bf16` (rows,), as WeightOnlyInt8QuantHandler.create_quantized_state_dict writes them
+ * (tools/llama/quantize.py:186-202).  name = the ".weight" key.  Arithmetic of the layer:
+ * bf16(bf16(x @ W_int8^T) * scales) (WeightOnlyInt8Linear.forward, quantize.py:228-229). */
+int fmi_dualar_load_tensor_int8(fmi_dualar* h, const char* name, const void* weight_i8, const void* scales_bf16,
+                                int64_t rows, int64_t cols, int src_is_device, void* stream);
 /* Call once after all tensors are loaded (rank 0 before the broadcast) to build derived
  * tables inside the arena (live LM-head rows, RoPE tables). */
 int fmi_dualar_finalize_weights(fmi_dualar* h, void* stream);
@@ -161,6 +170,13 @@ int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_fra
 int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_dev,
                        const void* residual_dev, void* out_dev, int M, int N, int K, float eps,
                        int epilogue, int force_path, void* stream);
+
+/* The same for a weight-only int8 linear: W int8 (N,K) row-major + per-row bf16 scales;
+ * out = epilogue(bf16(bf16(xn @ W^T) * scales)).  stream_int8: 1 = the decode GEMV streams the int8 tiles,
+ * 0 = it streams the exactly dequantised bf16 tiles (the two agree bit for bit).  M <= 16, K % 64 == 0. */
+int fmi_op_linear_int8(const void* x_dev, const void* w_i8_dev, const void* scales_dev, const void* norm_w_dev,
+                       const void* residual_dev, void* out_dev, int M, int N, int K, float eps, int epilogue,
+                       int stream_int8, void* stream);
 
 /* One sampler call on bf16 logits [B][ld] (n valid).  ids_dev: optional int32 map from row
  * index to vocab id.  prev_dev: optional RAS window row (B x 10 int32) -- when given, the

@@ -584,3 +584,79 @@ def test_s2_shape_forward_passes_match_the_cpu_oracle(s2_model):
         want_e = orc.fast_embeddings(a)
         assert torch.equal(model.fast_embeddings(a).cpu(), want_e)
         h = want_e.reshape(1, -1)
+
+
+# ------------------------------------------------------------------------------- weight-only int8 (8f #2)
+
+
+def _linear_int8(lib, x, wq, sc, norm_w, res, M, N, K, epi, stream_int8, eps=1e-6):
+    from fish_speech_amd._lib import check
+
+    n_out = N // 2 if epi == 2 else N
+    out = torch.zeros(M, n_out, dtype=torch.bfloat16, device=DEV)
+    t = [v.to(DEV) if v is not None else None for v in (x, wq, sc, norm_w, res)]
+    ptr = lambda v: C.c_void_p(v.data_ptr()) if v is not None else None
+    check(lib.fmi_op_linear_int8(ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), ptr(t[4]), C.c_void_p(out.data_ptr()),
+                                 M, N, K, eps, epi, stream_int8, None))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("N,K,epi,norm", [(19456, 2560, 2, True), (6144, 2560, 0, True), (2560, 4096, 1, False),
+                                          (2560, 9728, 1, False), (4096, 2560, 0, True), (192, 128, 0, True),
+                                          (320, 256, 2, False)])
+@pytest.mark.parametrize("M", [1, 8, 13])
+def test_int8_gemv_equals_the_dequantised_bf16_gemv_and_the_reference_arithmetic(lib, N, K, epi, norm, M):
+    """WeightOnlyInt8Linear (tools/llama/quantize.py:204-229): bf16(bf16(x @ W_int8^T) * scales).  Streaming the
+    int8 tiles and converting in registers gives the same bits as streaming the dequantised bf16 tiles (int8 ->
+    bf16 is exact), for 1 / 8 rows (int8 stream) and 13 rows (bf16 stream of the same model); and both match the
+    reference arithmetic evaluated on the CPU."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(N + K + M + epi)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    wq, sc = O.quantize_int8_per_channel(w)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16() if norm else None
+    res = torch.randn(M, N, generator=g).bfloat16() if epi == 1 else None
+    a = _linear_int8(lib, x, wq, sc, nw, res, M, N, K, epi, 1)
+    b = _linear_int8(lib, x, wq, sc, nw, res, M, N, K, epi, 0)
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    xin = O.rms_norm(x, nw, 1e-6) if norm else x
+    lin = lambda rows, srows: F.linear(xin, rows.to(torch.bfloat16)) * srows
+    if epi == 2:
+        h = N // 2
+        want = F.silu(lin(wq[:h], sc[:h])) * lin(wq[h:], sc[h:])
+    else:
+        y = lin(wq, sc)
+        want = res + y if epi == 1 else y
+    ok, mx, nbad = bf16_close(a, want, scale=res)
+    assert ok, (mx, nbad)
+    if M > 1:
+        one = _linear_int8(lib, x[:1].contiguous(), wq, sc, nw, None if res is None else res[:1].contiguous(), 1, N, K, epi, 1)
+        assert torch.equal(one[0], a[0])
+
+
+def test_int8_model_vs_the_reference_int8_fixture():
+    """The tiny model quantised by the reference's WeightOnlyInt8QuantHandler (fixture dualar_tiny_int8.npz): the
+    HIP path loaded from the int8 checkpoint (int8 tiles for decode, dequantised tiles for prefill, scales in the
+    epilogues), teacher-forced against the reference's traces, and free-running against the int8 oracle."""
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR, generate
+    from tests.helpers import check_teacher_forced
+
+    cfg, state, z = load_dualar_case("tiny_int8")
+    q = O.quantize_state_int8(cfg, state)
+    mcfg = DualARConfig.from_any(cfg)
+    mcfg.weight_int8 = True
+    model = MiDualAR(mcfg, device=DEV, im_end_id=cfg.im_end_id).load_state_dict(q)
+    model.setup_caches(2, cfg.max_seq_len)
+    st = check_teacher_forced(hip_step_fn(model, cfg, int(z["uniform_seed"])), cfg, z)
+    assert st["frames"] == z["greedy"].shape[1] - z["prompt"].shape[1] and st["exact"] >= 0.9 * st["decisions"]
+    with pytest.raises(ValueError):      # an int8 checkpoint needs the int8 arena
+        MiDualAR(DualARConfig.from_any(cfg), device=DEV, im_end_id=cfg.im_end_id).load_state_dict(q)
+    prompt = torch.from_numpy(z["prompt"])
+    got = generate(model=model, prompt=prompt, max_new_tokens=12, temperature=0.7, top_p=0.7, top_k=1, seed=1234).cpu()
+    want = O.generate(O.DualAROracle(cfg, q), prompt, 12, 0.7, 0.7, 1, uniform_fn=O.FmiUniform(1234, 0))
+    k = O.robust_prefix(torch.from_numpy(z["greedy_margins_ulps"]), 2.0)
+    T = prompt.shape[1]
+    assert torch.equal(got[:, : T + min(k, 12)], want[:, : T + min(k, 12)])
