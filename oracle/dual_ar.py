@@ -7,7 +7,7 @@ product path (``fish_speech_amd``) never does and fails loudly without its HIP l
 
 Parity pinning: the reference ships no tests or golden vectors, so this
 oracle is pinned against (a) the unmodified reference modules imported in the authoring
-container (``tests/test_oracle_vs_reference.py``, skipped where /root/reference is absent)
+container (``tests/test_oracle_cpu.py``: the live-reference tests are skipped where /root/reference is absent)
 and (b) fixtures those modules produced, committed under ``tests/golden/`` together with
 ``oracle/gen_golden.py``.
 

@@ -1,6 +1,6 @@
 """Helpers to import the UNMODIFIED reference modules (authoring container only).
 
-Test infrastructure: used by oracle/gen_golden.py and tests/test_oracle_vs_reference.py.  Nothing
+Test infrastructure: used by oracle/gen_golden*.py and tests/test_oracle_cpu.py / tests/test_dac_cpu.py.  Nothing
 here is reachable from the GPU-side tests, smoke() or bench.py (/root/reference does not exist on
 the GPU box)."""
 from __future__ import annotations
