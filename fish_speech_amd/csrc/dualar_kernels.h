@@ -43,7 +43,6 @@ int launch_pack_scale(const bf16_t* src, bf16_t* dst, int N, int interleave, hip
 // gather `n` rows listed in ids_dev (int32 vocab ids, on device) then pack (live LM-head rows).
 int launch_pack_rows_gather(const bf16_t* src, const int32_t* ids_dev, bf16_t* dst, int n, int n_pad,
                             int K, hipStream_t s);
-int launch_rope_table(bf16_t* dst, int seq_len, int head_dim, float base, hipStream_t s);
 
 struct LinearArgs {
   const bf16_t* wp;        // packed weights
@@ -93,6 +92,7 @@ struct AttnArgs {
   const int32_t* row_pos;   // [rows] or nullptr -> SlotState.pos[slot]
   const int32_t* block_table;
   const int32_t* slot_pos;
+  const int32_t* slot_done;   // decode only: a finished slot (SlotState.done != 0) no longer appends K/V
   int max_pages;
   int rows, H, KVH, D;
   float eps;

@@ -1064,7 +1064,9 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
         s_q[item - 2][2 * p] = bf2f(o0);
         s_q[item - 2][2 * p + 1] = bf2f(o1);
       } else {
-        if (gz == 0) {  // every split recomputes the new k/v row for its LDS copy; one of them appends it
+        // every split recomputes the new k/v row for its LDS copy; one of them appends it -- unless the slot has
+        // finished (its position no longer advances and may sit one past the pages it reserved)
+        if (gz == 0 && !(a.slot_done && a.slot_done[slot])) {
           const int page = bt[pos / KV_PAGE];
           bf16_t* pool = (item == 0) ? a.kpool : a.vpool;
           *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kvh) * KV_PAGE + pos % KV_PAGE) * D + 2 * p) =

@@ -29,7 +29,8 @@ DUALAR_CASES = {
 }
 
 
-def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None, trace=None, int8=False):
+def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None, trace=None, int8=False, temperature=0.7,
+                  top_p=0.7):
     """Run the reference's generate(); optionally record, per frame, what its own functions saw:
     the slow logits + hidden state (forward_generate) and every fast logits row (sample())."""
     add_reference_to_path()
@@ -94,7 +95,7 @@ def _ref_generate(cfg, state, prompt, max_new, top_k, uniform=None, trace=None, 
         if uniform is not None:
             torch.rand_like = lambda t, **kw: uniform(t.shape[-1], t.dtype)
         y = RI.generate(model=ref, prompt=prompt, max_new_tokens=max_new, audio_masks=None, audio_parts=None,
-                        decode_one_token=dec, temperature=0.7, top_p=0.7, top_k=top_k)
+                        decode_one_token=dec, temperature=temperature, top_p=top_p, top_k=top_k)
     finally:
         torch.rand_like = orig_rand
         torch.sort = orig_sort
@@ -143,11 +144,72 @@ def gen_dualar(only_int8=False):
               tuple(fast.shape), "robust prefix", O.robust_prefix(margins), "of", len(margins))
 
 
+# Well-conditioned free-running fixtures: seeds found by `python -m oracle.search_golden` (every decision of the
+# run has >= 8 bf16 steps of margin / is invariant under 2 steps of logit noise); see make_peaky_state.
+from .search_golden import MID as _MID  # noqa: E402
+
+PEAKY_CASES = {
+    # name: (config kwargs, make_peaky_state kwargs, prompt (T, n_semantic, seed), max_new, sampling (T, top_p, top_k), uniform seed)
+    "tiny_peaky": ({}, dict(seed=1, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5), (24, 8, 1), 64, (0.7, 0.7, 1), 1234),
+    "tiny_peaky_eos": ({}, dict(seed=8, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5, eos_code=17), (24, 8, 2), 96,
+                       (0.7, 0.7, 1), 1234),
+    "mid_peaky": (_MID, dict(seed=93, emb_gain=2.5, slow_gain=3.0, fast_gain=2.5), (40, 12, 3), 48, (0.7, 0.7, 1), 1234),
+    "tiny_sampled": ({}, dict(seed=3, emb_gain=6.0, slow_gain=2.0, fast_gain=8.0, hot=(1.0, 0.95, 0.93), hot_every=3),
+                     (24, 8, 3), 40, (0.7, 0.9, 30), 67),
+}
+MIN_MARGIN_ULPS = 8.0
+
+
+def gen_dualar_peaky():
+    import json
+
+    from .search_golden import sampled_run_is_robust
+
+    for name, (kw, skw, (T, nsem, pseed), max_new, (temp, top_p, top_k), useed) in PEAKY_CASES.items():
+        cfg = O.DualARConfig(**kw)
+        state = O.make_peaky_state(cfg, **skw)
+        prompt = O.make_prompt(cfg, T, seed=pseed, n_semantic=nsem)
+        tr = {}
+        tokens = _ref_generate(cfg, state, prompt, max_new, top_k, O.FmiUniform(seed=useed, stream=0), trace=tr,
+                               temperature=temp, top_p=top_p)
+        n = tokens.shape[1] - T
+        # the oracle must reproduce the reference run bit for bit on this machine
+        orc = O.DualAROracle(cfg, state)
+        mine = O.generate(orc, prompt, max_new, temp, top_p, top_k, uniform_fn=O.FmiUniform(useed, 0))
+        assert torch.equal(mine, tokens), name
+        ids = live_ids(cfg)
+        slow_full = torch.stack(tr["slow_logits"])
+        slow = slow_full[:, ids]
+        hidden = torch.stack(tr["hidden"])
+        fast = torch.stack([torch.stack(f) for f in tr["fast_logits"]])
+        margins = O.greedy_frame_margins(cfg, slow, fast)
+        if top_k == 1:
+            assert float(margins.min()) >= MIN_MARGIN_ULPS, (name, float(margins.min()))
+            assert O.robust_prefix(margins, MIN_MARGIN_ULPS) == n
+            note = f"min margin {float(margins.min()):.1f} ulps"
+        else:
+            rtr = {"slow_logits": list(slow_full), "fast_logits": [list(f) for f in fast]}
+            ok, non_top1, ras = sampled_run_is_robust(cfg, tokens, rtr, T, temp, top_p, top_k, useed)
+            assert ok and non_top1 >= 4 and ras >= 1, (name, ok, non_top1, ras)
+            note = f"every decision invariant under 2 steps of logit noise; {non_top1} non-top-1 slow tokens, RAS fired {ras}x"
+        np.savez_compressed(
+            os.path.join(OUT, f"dualar_{name}.npz"), prompt=prompt.numpy(), tokens=tokens.numpy(),
+            state_kind="peaky", state_kwargs=json.dumps(skw), max_new=max_new, uniform_seed=useed,
+            temperature=temp, top_p=top_p, top_k=top_k,
+            cfg_keys=np.array(list(kw.keys())), cfg_vals=np.array([float(v) for v in kw.values()]),
+            live_ids=ids.numpy(), slow_logits_live=_u16(slow), hidden=_u16(hidden), fast_logits=_u16(fast),
+            greedy_margins_ulps=margins.numpy())
+        ended = "ended by <|im_end|>" if int(tokens[0, -1]) == cfg.im_end_id else "ran to max_new"
+        print(name, tuple(tokens.shape), f"{n} frames, {ended};", note)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["dualar", "dac"]
     if "dualar" in which:
         gen_dualar()
+    if "peaky" in which or "dualar" in which:
+        gen_dualar_peaky()
     if "int8" in which:
         gen_dualar(only_int8=True)
     if "dac" in which:

@@ -17,8 +17,20 @@ def load_dualar_case(name: str):
     for k, v in zip(z["cfg_keys"], z["cfg_vals"]):
         kw[str(k)] = int(v)
     cfg = O.DualARConfig(**kw)
-    state = O.make_synthetic_state(cfg, seed=int(z["state_seed"]), head_gain=float(z["head_gain"]))
+    if "state_kind" in z.files and str(z["state_kind"]) == "peaky":   # well-conditioned fixtures (make_peaky_state)
+        import json
+
+        skw = json.loads(str(z["state_kwargs"]))
+        if "hot" in skw:
+            skw["hot"] = tuple(skw["hot"])
+        state = O.make_peaky_state(cfg, **skw)
+    else:
+        state = O.make_synthetic_state(cfg, seed=int(z["state_seed"]), head_gain=float(z["head_gain"]))
     return cfg, state, z
+
+
+PEAKY_GREEDY = ["tiny_peaky", "tiny_peaky_eos", "mid_peaky"]
+PEAKY_ALL = PEAKY_GREEDY + ["tiny_sampled"]
 
 
 def bf16_from_u16(a: np.ndarray) -> torch.Tensor:
@@ -74,7 +86,7 @@ def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float
     Returns statistics for reporting."""
     from oracle import dual_ar as O
 
-    seq = torch.from_numpy(z["greedy"])
+    seq = torch.from_numpy(z["greedy"] if "greedy" in z.files else z["tokens"])
     prompt = torch.from_numpy(z["prompt"])
     T = prompt.shape[1]
     ncb1 = cfg.num_codebooks + 1

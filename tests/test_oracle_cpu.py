@@ -43,6 +43,34 @@ def test_oracle_free_running_vs_reference_golden(case, mode, top_k):
     assert np.array_equal(y[:, : T + k], want[:, : T + k])
 
 
+@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled"])
+def test_well_conditioned_fixtures_full_sequence_and_margins(case):
+    """The well-conditioned fixtures (oracle.make_peaky_state; written by the unmodified reference's generate()):
+    every decision of the reference run has >= 8 bf16 steps of margin (greedy) -- re-derived here from the stored
+    reference traces --, so ANY correct bf16 implementation must reproduce the WHOLE token sequence, on any CPU:
+    the oracle does, free-running (greedy and sampled), and teacher-forced with exact == decisions."""
+    from tests.helpers import bf16_from_u16, check_teacher_forced, oracle_step_fn
+
+    cfg, state, z = load_dualar_case(case)
+    want = z["tokens"]
+    T = z["prompt"].shape[1]
+    n = want.shape[1] - T
+    top_k = int(z["top_k"])
+    assert n >= 40
+    if top_k == 1:
+        m = O.greedy_frame_margins(cfg, bf16_from_u16(z["slow_logits_live"]), bf16_from_u16(z["fast_logits"]))
+        assert float(m.min()) >= 8.0 and O.robust_prefix(m, 8.0) == n
+        assert np.array_equal(m.numpy(), z["greedy_margins_ulps"])
+    y = O.generate(O.DualAROracle(cfg, state), torch.from_numpy(z["prompt"]), int(z["max_new"]), float(z["temperature"]),
+                   float(z["top_p"]), top_k, uniform_fn=O.FmiUniform(int(z["uniform_seed"]), 0)).numpy()
+    assert y.shape == want.shape and np.array_equal(y, want)
+    if case == "tiny_peaky_eos":
+        assert n < int(z["max_new"]) and int(want[0, -1]) == cfg.im_end_id
+    if top_k == 1:
+        st = check_teacher_forced(oracle_step_fn(cfg, state, int(z["uniform_seed"])), cfg, z)
+        assert st["frames"] == n and st["exact"] == st["decisions"] == n * cfg.num_codebooks
+
+
 def test_generate_bounds_match_reference_errors():
     cfg = O.DualARConfig()
     orc = O.DualAROracle(cfg, O.make_synthetic_state(cfg, 0))
