@@ -156,6 +156,18 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=5, codec_frames=32):
     orc = O.DualAROracle(oc, st)
     prompt = make_prompts(cfg, 1, 1000)[0]
     orc.setup_caches(1, oc.max_seq_len)
+    # the bf16 CPU path is memory-bound and oversubscribes badly: sweep the thread count on two decode frames each
+    # and time the sample with the best one (the reference's own default is torch's, i.e. every core)
+    all_threads = torch.get_num_threads()
+    sweep = {}
+    O.generate(orc, prompt[:, :8], 1, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)  # page in
+    for nt in sorted({t for t in (8, 16, 32, 64, 128, all_threads) if t <= all_threads}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        O.generate(orc, prompt[:, :8], 3, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
+        sweep[nt] = (time.perf_counter() - t0) / 3
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
     O.generate(orc, prompt, 1, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
     t_prefill = time.perf_counter() - t0
@@ -172,17 +184,158 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=5, codec_frames=32):
         corc = OD.DacOracle(ccfg, cst)
         codes = OD.make_codes(ccfg, 1, codec_frames, seed=1)
         with torch.no_grad():
-            t0 = time.perf_counter()
-            corc.from_indices(codes)
-            t_c = time.perf_counter() - t0
+            t_c = 1e30
+            for nt in sorted({t for t in (16, 64, all_threads) if t <= all_threads}):
+                torch.set_num_threads(nt)
+                t0 = time.perf_counter()
+                corc.from_indices(codes.clone())
+                t_c = min(t_c, time.perf_counter() - t0)
         t_codec = t_c * N_FRAMES / codec_frames
         note = f"codec decode {codec_frames} frames {t_c:.2f}s (fp32)"
+    torch.set_num_threads(all_threads)
     return {
-        "value": round(10.0 / (t_ar + t_codec), 5), "unit": "audio-sec/s", "cores": torch.get_num_threads(),
+        "value": round(10.0 / (t_ar + t_codec), 5), "unit": "audio-sec/s", "cores": best,
         "kind": "port",
-        "sample": f"oracle on torch CPU, batch 1: prefill {PROMPT_T} tokens {t_prefill:.2f}s + {n_frames} decode "
+        "sample": f"oracle on torch CPU, batch 1, {best} threads (best of sweep "
+                  f"{ {k: round(v, 2) for k, v in sweep.items()} } s/frame-ish, host has {os.cpu_count()} cpus): "
+                  f"prefill {PROMPT_T} tokens {t_prefill:.2f}s + {n_frames} decode "
                   f"frames at {per_frame:.3f}s/frame (bf16); {note}; extrapolated to one {N_FRAMES}-frame utterance",
     }
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def mixed_length_workload(cfg, n_utts, seed=2024):
+    """BASELINE.json config 4 / SURVEY.md 8d: prompts T ~ U{50..400}, frames ~ U{100..430} per utterance."""
+    g = torch.Generator().manual_seed(seed)
+    prompts, frames = [], []
+    for _ in range(n_utts):
+        T = int(torch.randint(50, 401, (1,), generator=g))
+        n = int(torch.randint(100, 431, (1,), generator=g))
+        p = torch.zeros(cfg.num_codebooks + 1, T, dtype=torch.int64)
+        p[0] = torch.randint(0, 150000, (T,), generator=g)
+        prompts.append(p)
+        frames.append(n)
+    return prompts, frames
+
+
+def run_config4(model, codec, cfg, rank, world, dist, device):
+    """Config 4: a global queue of 8 x world mixed-length utterances, LPT-packed over the ranks by expected frames
+    (scheduler.partition_for_ranks -- no data-path collective), each rank running its share through continuous
+    batching (8 slots, finished slots refilled) and decoding every utterance's codes with the codec."""
+    from fish_speech_amd.scheduler import generate_queue, lpt_order, partition_for_ranks
+
+    prompts, frames = mixed_length_workload(cfg, BATCH * world)
+    mine = partition_for_ranks([f + 0.1 * p.shape[1] for p, f in zip(prompts, frames)], world)[rank]
+    ps, fr = [prompts[i] for i in mine], [frames[i] for i in mine]
+    seeds = [9000 + i for i in mine]
+
+    def once():
+        res = generate_queue(model=model, prompts=ps, max_new_tokens=fr, max_batch=BATCH, seeds=seeds,
+                             order=lpt_order(fr), temperature=0.7, top_p=0.7, top_k=30)
+        n = 0
+        for r, p, f in zip(res, ps, fr):
+            codes = r[1:, p.shape[1]:].to(device).unsqueeze(0).contiguous()
+            assert codes.shape[-1] == f
+            if codec is not None:
+                codec.from_indices(codes)
+            n += f
+        _sync(device)
+        return n
+
+    once()                                   # warm-up (graphs for every live-slot count)
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_frames = once()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, dt, float(n_frames)], device=device, dtype=torch.float64)
+    if dist:
+        mx = t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt_max, dt_mean, total = float(mx[0]), float(t[1]) / world, float(t[2])
+    else:
+        dt_max, dt_mean, total = dt, dt, float(n_frames)
+    return {"workload": f"configs[3]: {BATCH * world} mixed-length utterances (T~U[50,400], frames~U[100,430]) over "
+                        f"{world} GPU(s), LPT-partitioned, continuous batching with {BATCH} slots + per-utterance codec decode",
+            "audio_sec_per_s": round(total * FRAME_LEN / SAMPLE_RATE / dt_max, 2), "wall_s": round(dt_max, 3),
+            "frames_total": int(total),
+            "rank_imbalance_max_over_mean": round(dt_max / dt_mean, 4)}
+
+
+def run_config1(model, codec, cfg, device):
+    """Config 1 (BASELINE configs[1]): one utterance, greedy, 200-token prompt -> 215 frames + codec decode."""
+    from fish_speech_amd.dual_ar import generate_batch_device
+
+    p = make_prompts(cfg, 1, 5000)
+
+    def once():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        codes = generate_batch_device(model=model, prompts=p, max_new_tokens=N_FRAMES, seeds=[1], temperature=0.7,
+                                      top_p=0.7, top_k=1)
+        ms, _ = model.last_decode_stats()
+        if codec is not None:
+            codec.from_indices(codes)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ms / max(N_FRAMES - 1, 1)
+
+    once()
+    dt, frame_ms = min(once() for _ in range(2))
+    return {"workload": "configs[1]: single utterance greedy decode + codec, batch=1", "latency_s": round(dt, 4),
+            "audio_sec_per_s": round(N_FRAMES * FRAME_LEN / SAMPLE_RATE / dt, 2), "decode_frame_ms": round(frame_ms, 4)}
+
+
+def run_config5(model, codec, cfg, device, runs=5, first=8, chunk=32):
+    """Config 5: streaming chunked decode at batch 8 -- p50 wall time until the first audio chunk is complete."""
+    import statistics
+
+    from fish_speech_amd.stream import generate_stream
+
+    prompts = make_prompts(cfg, BATCH, 1000)
+    seeds = [4242 + i for i in range(BATCH)]
+
+    def once():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first_t, n = None, 0
+        for ch in generate_stream(model=model, codec=codec, prompts=prompts, max_new_tokens=N_FRAMES + 1,
+                                  first_chunk_frames=first, chunk_frames=chunk, seeds=seeds, temperature=0.7,
+                                  top_p=0.7, top_k=30):
+            torch.cuda.synchronize()
+            if first_t is None:
+                first_t = time.perf_counter() - t0
+            n += ch.audio.shape[-1]
+        return first_t, time.perf_counter() - t0, n
+
+    once()
+    rs = [once() for _ in range(runs)]
+    tot = statistics.median(r[1] for r in rs)
+    return {"workload": f"configs[4]: streaming, batch=8, first chunk {first} frames then every {chunk}",
+            "first_audio_ms_p50": round(statistics.median(r[0] for r in rs) * 1e3, 2),
+            "stream_audio_sec_per_s": round(BATCH * rs[0][2] / SAMPLE_RATE / tot, 2)}
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node -- refusing to report a "
+                         f"{n}-GPU number from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -196,12 +349,16 @@ def main():
                     help="weight-only int8 checkpoint of the same model (NOT the headline number: reduced precision)")
     ap.add_argument("--no-codec", action="store_true", help="debug: Dual-AR only (INVALID as a result)")
     ap.add_argument("--frames", type=int, default=215, help="debug: fewer frames (INVALID as a result)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra measurements (configs 1, 3, 4 of BASELINE.json) after the timed region")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -231,7 +388,7 @@ def main():
         from fish_speech_amd.dist import broadcast_arena
 
         broadcast_arena(model, src=0)
-    model.setup_caches(BATCH, PROMPT_T + N_FRAMES + 8)
+    model.setup_caches(BATCH, cfg.max_seq_len)   # 1024 positions per slot: covers config 3's 400 + 430
     model.set_ignore_eos(True)
     codec, codec_state = None, None
     if not args.no_codec:
@@ -312,6 +469,13 @@ def main():
                                "10 sampler launches, replayed as one hipGraph",
                      "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},
     }
+    if not args.no_extras and N_FRAMES == 215:
+        # untimed extras: the other single-node configurations of BASELINE.json, measured with the same objects
+        extras = {"config3_mixed_lengths": run_config4(model, codec, cfg, rank, world, dist, device)}
+        if world == 1 and codec is not None:
+            extras["config1_batch1_greedy"] = run_config1(model, codec, cfg, device)
+            extras["config4_streaming"] = run_config5(model, codec, cfg, device)
+        out["other_configs"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, state, codec_state)
     if rank == 0:

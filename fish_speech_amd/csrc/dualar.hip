@@ -67,7 +67,8 @@ struct fmi_dualar {
   Workspace ws;
   bf16_t *hn = nullptr, *hf = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
   bool trace = false, use_graph = true, ignore_eos = false;
-  int max_top_k = 0;  // largest top_k any live slot was configured with (selects the sampler variant)
+  int max_top_k = 0;  // largest top_k over the LIVE slots (selects the sampler variant the graphs embed)
+  std::vector<int> slot_top_k;  // per slot, 0 = released
   std::map<int, hipGraphExec_t> graphs;
   void* staging = nullptr;
   size_t staging_bytes = 0;
@@ -266,7 +267,7 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
   a.qnw = h->cfg.attention_qk_norm ? w.q_norm : nullptr;
   a.knw = h->cfg.attention_qk_norm ? w.k_norm : nullptr;
   a.rope = h->rope; a.row_slot = row_slot; a.row_pos = row_pos; a.block_table = h->st.block_table;
-  a.slot_pos = h->st.pos; a.max_pages = h->max_pages; a.rows = rows; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
+  a.slot_pos = h->st.pos; a.slot_done = row_pos == nullptr ? h->st.done : nullptr; a.max_pages = h->max_pages; a.rows = rows; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
   a.eps = h->cfg.norm_eps;
   if (row_pos == nullptr) {  // decode: one row per slot -> fused prep + attention
     FMI_CHECK(launch_attn_decode_fused(a, s));
@@ -391,11 +392,14 @@ int reserve_pages(fmi_dualar* h, int slot, int upto_pos_exclusive) {
 
 int set_slot(fmi_dualar* h, int slot, int pos, int frame, int limit, const fmi_sampling& sp, bool zero_window) {
   hipStream_t s = h->stream;
-  if ((sp.top_k > 64) != (h->max_top_k > 64)) {  // the captured graphs embed the sampler variant
+  h->slot_top_k[slot] = (int)sp.top_k;
+  int mk = 0;
+  for (int k : h->slot_top_k) mk = std::max(mk, k);
+  if ((mk > 64) != (h->max_top_k > 64)) {  // the captured graphs embed the sampler variant
     FMI_CHECK_HIP(hipStreamSynchronize(s));
     drop_graphs(h);
   }
-  h->max_top_k = std::max(h->max_top_k, (int)sp.top_k);
+  h->max_top_k = mk;
   const int32_t zero = 0;
   const float t = rbf(sp.temperature), p = rbf(sp.top_p);
 #define PUT(arr, val) FMI_CHECK_HIP(hipMemcpyAsync((arr) + slot, &(val), 4, hipMemcpyHostToDevice, s))
@@ -736,6 +740,8 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
   h->free_pages.clear();
   for (int p = h->n_pages - 1; p >= 0; --p) h->free_pages.push_back(p);
   h->slot_pages.assign(max_batch, {});
+  h->slot_top_k.assign(max_batch, 0);
+  h->max_top_k = 0;
   return ensure_rows(h, max_batch);
 }
 
@@ -744,6 +750,7 @@ int fmi_dualar_release(fmi_dualar* h, int slot) {
   FMI_CHECK(check_slot(h, slot));
   for (int p : h->slot_pages[slot]) h->free_pages.push_back(p);
   h->slot_pages[slot].clear();
+  h->slot_top_k[slot] = 0;   // the sampler variant is re-derived from the live slots at the next set_slot
   return FMI_OK;
 }
 
@@ -766,7 +773,10 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
     int mn = max_new[i];
     if (mn <= 0 || lens[i] + mn > h->max_seq) mn = h->max_seq - lens[i];  // inference.py:268-275
     const int limit = lens[i] + mn - 1;
-    FMI_CHECK(reserve_pages(h, slot_ids[i], std::max(limit, lens[i])));
+    // positions 0..limit-1 receive K/V; a slot that ends AT its limit parks its position counter on `limit`, so
+    // the block-table entry of that position must be the slot's own page too (the decode attention additionally
+    // stops appending once SlotState.done is set)
+    FMI_CHECK(reserve_pages(h, slot_ids[i], std::min(std::max(limit, lens[i]) + 1, h->max_seq)));
     FMI_CHECK(set_slot(h, slot_ids[i], lens[i], frame_index, limit, samp[i], frame_index == 0));
     for (int t = 0; t < lens[i]; ++t, ++r) {
       row_slot[r] = slot_ids[i];
@@ -950,8 +960,11 @@ int fmi_dualar_forward_slow(fmi_dualar* h, int slot, const int32_t* x_dev, int S
   }
   if (logits_out_dev)
     FMI_CHECK_HIP(hipMemcpyAsync(logits_out_dev, h->logits, (size_t)h->n_live * 2, hipMemcpyDeviceToDevice, s));
-  if (hidden_out_dev)
-    FMI_CHECK_HIP(hipMemcpyAsync(hidden_out_dev, h->hn, (size_t)h->cfg.dim * 2, hipMemcpyDeviceToDevice, s));
+  if (hidden_out_dev) {
+    // llama.py:459-461: hidden_states = slow_out (normed) if norm_fastlayer_input else the un-normed last row
+    const bf16_t* hid = h->cfg.norm_fastlayer_input ? h->hn : ((S > 1 || pos0 == 0) ? h->xl : h->ws.x);
+    FMI_CHECK_HIP(hipMemcpyAsync(hidden_out_dev, hid, (size_t)h->cfg.dim * 2, hipMemcpyDeviceToDevice, s));
+  }
   return sync_out(h, stream);
 }
 

@@ -145,10 +145,8 @@ int launch_pack_rows_gather(const bf16_t* src, const int32_t* ids_dev, bf16_t* d
   return FMI_OK;
 }
 
-// RoPE table, llama.py:1004-1023: angle = pos * base^(-2k/D) in fp32, cos/sin rounded to bf16.
-// The table is built on the HOST with the same libm family torch uses on CPU (cosf/sinf of a
-// fp32 angle) so that the bf16-rounded entries agree with the reference's; see dualar.hip.
-int launch_rope_table(bf16_t*, int, int, float, hipStream_t) { return FMI_OK; }
+// The RoPE table (llama.py:1004-1023) is built by the host mirror with torch, exactly as the reference does, and
+// loaded through fmi_dualar_load_tensor ("rope", "fast_rope"); there is no device-side table kernel.
 
 // =====================================================================================
 // embedding (llama.py:400-420)

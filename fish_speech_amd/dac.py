@@ -331,18 +331,3 @@ class MiDAC:
         check(self.lib.fmi_dac_debug_z(self._h, C.byref(p), C.byref(cc), C.byref(ll)))
         torch.cuda.synchronize(self.device)
         return _from_ptr(p.value, (B, cc.value, ll.value), torch.float32, self.device).clone()
-
-
-def smoke_check():
-    """Used by __graft_entry__.smoke(): tiny codec, from_indices vs the CPU oracle."""
-    from oracle import dac as D
-
-    cfg = D.small_config()
-    state = D.make_synthetic_state(cfg, seed=11)
-    codec = MiDAC.from_state_dict(DacConfig.from_any(cfg), state)
-    codes = D.make_codes(cfg, 1, 4, seed=2)
-    got = codec.from_indices(codes.clone().cuda()).cpu()
-    want = D.DacOracle(cfg, state).from_indices(codes.clone())
-    rms = float((got - want).pow(2).mean().sqrt())
-    assert rms <= 1e-4, f"codec waveform RMS error {rms}"
-    print(f"smoke: codec from_indices RMS error vs oracle {rms:.2e}")

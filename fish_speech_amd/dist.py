@@ -36,11 +36,11 @@ def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_bytes: int = 1 << 30
         dist.broadcast(flat[off: min(n, off + chunk_bytes)], src=src, group=group)
 
 
-def broadcast_arena(model, src: int = 0, group=None):
+def broadcast_arena(model, src: int = 0, group=None, chunk_bytes: int = 1 << 30):
     """Replicate a loaded model's packed weight arena to every rank, then mark it ready there."""
     import torch.distributed as dist
 
-    broadcast_buffer(model.arena, src=src, group=group)
+    broadcast_buffer(model.arena, src=src, chunk_bytes=chunk_bytes, group=group)
     if dist.get_rank(group) != src:
         model.weights_ready()
 

@@ -219,6 +219,7 @@ class MiDualAR:
         self.max_batch_size = -1
         self.max_seq_len = -1
         self._frame_index = 0
+        self._ignore_eos = False
         self._seed_counter = itertools.count()
         self._dtype_probe = torch.empty(0, dtype=torch.bfloat16, device=self.device)
         self.fixed_temperature = torch.tensor(0.7, device=self.device)
@@ -373,6 +374,7 @@ class MiDualAR:
         ncb1 = cfg.num_codebooks + 1
         xs = x.reshape(ncb1, -1).t().to(device=self.device, dtype=torch.int32).contiguous()
         pos0 = 0 if input_pos is None else int(input_pos.reshape(-1)[0].item())
+        self._check_tokens(xs)
         ids = self._table(1, torch.int32).view(-1).long()
         live = torch.empty(ids.numel(), dtype=torch.bfloat16, device=self.device)
         hidden = torch.empty(cfg.dim, dtype=torch.bfloat16, device=self.device)
@@ -402,11 +404,23 @@ class MiDualAR:
     def next_seed(self) -> int:
         return (torch.initial_seed() + 0x9E37 * next(self._seed_counter)) & 0xFFFFFFFF
 
+    def _check_tokens(self, rows: torch.Tensor):
+        """rows: (S, 1+ncb) integer.  The embedding kernel gathers E[row 0] and CB[code + i*codebook_size] without
+        bounds checks; the reference's nn.Embedding raises IndexError on an out-of-range id, so do the same here
+        (row 0 in [0, vocab), code rows in [0, codebook_size) -- they index the shared codebook table, llama.py:403)."""
+        cfg = self.config
+        t0, codes = rows[:, 0], rows[:, 1:]
+        if rows.numel() and (int(t0.min()) < 0 or int(t0.max()) >= cfg.vocab_size):
+            raise IndexError(f"token id out of range [0, {cfg.vocab_size})")
+        if codes.numel() and (int(codes.min()) < 0 or int(codes.max()) >= cfg.codebook_size):
+            raise IndexError(f"codebook index out of range [0, {cfg.codebook_size})")
+
     def prefill(self, slots: Sequence[int], prompts: Sequence[torch.Tensor], max_new_tokens: Sequence[int],
                 sampling: Sequence[SamplingC]):
         """prompts[i]: (1+ncb, T_i) integer tensor (the reference's prompt layout)."""
         n = len(slots)
         toks = torch.cat([p.to(self.device).t().to(torch.int32) for p in prompts], dim=0).contiguous()
+        self._check_tokens(toks)
         lens = (C.c_int32 * n)(*[int(p.shape[1]) for p in prompts])
         sl = (C.c_int32 * n)(*[int(s) for s in slots])
         mn = (C.c_int32 * n)(*[int(m) for m in max_new_tokens])
@@ -459,6 +473,7 @@ class MiDualAR:
     def set_ignore_eos(self, enable: bool):
         """Keep generating past <|im_end|> (fixed-length synthetic benchmarks)."""
         check(self.lib.fmi_dualar_set_ignore_eos(self._h, int(enable)))
+        self._ignore_eos = bool(enable)
 
     # ---- parity taps
     def debug_taps(self, B: int = 1):
@@ -490,6 +505,7 @@ class MiDualAR:
              frame_index: int, slot: int = 0) -> torch.Tensor:
         """One frame for one slot = the decode_one_token seam.  x: (S, 1+ncb) int32 on device."""
         ncb1 = self.config.num_codebooks + 1
+        self._check_tokens(x)
         out = torch.empty(ncb1, dtype=torch.int32, device=self.device)
         prev = None
         if previous_tokens is not None:
@@ -518,13 +534,34 @@ def _from_ptr(ptr: int, shape, dtype, device) -> torch.Tensor:
 # --------------------------------------------------------------------------- reference-shaped callables
 
 
+def _require_default_bias(model: MiDualAR, bias: torch.Tensor):
+    """The library scores only the rows generate() leaves finite (inference.py:310-320: 0 on the semantic ids and
+    <|im_end|>, -inf elsewhere).  A caller-supplied bias is accepted only if it IS that mask; anything else would be
+    silently ignored, so it is refused."""
+    key = (bias.data_ptr(), tuple(bias.shape))
+    if getattr(model, "_bias_ok", None) == key:
+        return
+    cfg = model.config
+    b = bias.detach().reshape(-1).float().cpu()
+    want = torch.full((cfg.vocab_size,), float("-inf"))
+    want[cfg.semantic_begin_id: cfg.semantic_end_id + 1] = 0.0
+    want[cfg.im_end_id] = 0.0
+    if b.numel() != cfg.vocab_size or not torch.equal(b, want):
+        raise NotImplementedError("fish_speech_amd.decode_one_token only supports the semantic_logit_bias that "
+                                  "generate() builds (0 on semantic ids and <|im_end|>, -inf elsewhere)")
+    model._bias_ok = key
+
+
 def decode_one_token(model: MiDualAR, x: torch.Tensor, input_pos: torch.Tensor, temperature, top_p, top_k: int,
                      semantic_logit_bias=None, audio_masks=None, audio_parts=None,
                      previous_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Drop-in for decode_one_token_ar (inference.py:96-181): same arguments, same (1+ncb, 1) int
     result.  ``semantic_logit_bias`` is implied by the config (only semantic ids + <|im_end|> are ever
-    scored: the algorithmic minimum of the reference's -inf bias); audio_* are dead for S2."""
+    scored: the algorithmic minimum of the reference's -inf bias); passing that very mask is accepted, any other
+    bias raises NotImplementedError instead of being ignored; audio_* are dead for S2."""
     ncb1 = model.config.num_codebooks + 1
+    if semantic_logit_bias is not None:
+        _require_default_bias(model, semantic_logit_bias)
     xs = x.reshape(ncb1, -1).t().to(device=model.device, dtype=torch.int32).contiguous()
     S = xs.shape[0]
     pos0 = int(input_pos.reshape(-1)[0].item())
@@ -603,6 +640,14 @@ def generate_batch_device(*, model: MiDualAR, prompts: Sequence[torch.Tensor], m
     n = len(prompts)
     if not model._cache_setup_done:
         model.setup_caches(max_batch_size=n, max_seq_len=cfg.max_seq_len)
+    if max_new_tokens < 1:
+        raise ValueError("generate_batch_device needs an explicit max_new_tokens >= 1")
+    for p in prompts:   # every slot must really produce max_new_tokens frames, or the returned block holds stale rows
+        if p.size(1) + max_new_tokens > model.max_seq_len:
+            raise ValueError(f"prompt of {p.size(1)} tokens + {max_new_tokens} new exceeds max_seq_len {model.max_seq_len}")
+    if not model._ignore_eos:
+        raise ValueError("generate_batch_device returns a fixed-length block: call model.set_ignore_eos(True) first "
+                         "(or use generate_batch, which returns per-utterance lengths)")
     slots = list(range(n))
     seeds = list(seeds) if seeds is not None else [model.next_seed() for _ in range(n)]
     samp = [model._sampling(temperature, top_p, top_k, seeds[i], use_ras) for i in range(n)]

@@ -36,14 +36,16 @@ def partition_for_ranks(costs: Sequence[float], world: int) -> List[List[int]]:
 
 
 @torch.no_grad()
-def generate_queue(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_tokens: int,
+def generate_queue(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_tokens,
                    max_batch: Optional[int] = None, poll_every: int = 16, seeds: Optional[Sequence[int]] = None,
                    order: Optional[Sequence[int]] = None, temperature: float = 1.0, top_p: float = 0.9,
                    top_k: int = 30, use_ras: bool = True, stats: Optional[dict] = None) -> List[torch.Tensor]:
     """Run all `prompts` through `max_batch` slots with refill; returns, per utterance (in input order),
-    (1+ncb, T_i + n_i) like the reference's `generate`."""
+    (1+ncb, T_i + n_i) like the reference's `generate`.  `max_new_tokens`: one int, or one per utterance."""
     cfg = model.config
     n = len(prompts)
+    per_utt = [int(max_new_tokens)] * n if isinstance(max_new_tokens, int) else [int(m) for m in max_new_tokens]
+    assert len(per_utt) == n
     for p in prompts:
         if p.size(1) >= cfg.max_seq_len:  # inference.py:263-266
             raise ValueError(f"Input sequence length {p.size(1)} exceeds max_seq_len {cfg.max_seq_len}")
@@ -65,8 +67,8 @@ def generate_queue(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_
             new_idx.append(pending.pop())
         if new_slots:
             ps = [prompts[i] for i in new_idx]
-            mn = [min(max_new_tokens if max_new_tokens else cfg.max_seq_len - p.size(1), cfg.max_seq_len - p.size(1))
-                  for p in ps]
+            mn = [min(per_utt[i] if per_utt[i] else cfg.max_seq_len - p.size(1), cfg.max_seq_len - p.size(1))
+                  for i, p in zip(new_idx, ps)]
             samp = [model._sampling(temperature, top_p, top_k, seeds[i], use_ras) for i in new_idx]
             model.prefill(new_slots, ps, mn, samp)
             active.update(zip(new_slots, new_idx))
