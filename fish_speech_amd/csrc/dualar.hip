@@ -66,6 +66,11 @@ struct fmi_dualar {
   std::vector<std::vector<int>> slot_pages;
   Workspace ws;
   bf16_t *hn = nullptr, *hf = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
+  // fast layer 0 sees fast_embeddings[code] at every codebook position >= 1, so its wqkv(rmsnorm(.)) output is a
+  // pure function of the code: tabulated once with the same GEMV kernel (batch-invariant bits), gathered by the
+  // sampler; 9 of the 40 fast wqkv GEMVs of a frame (31.5 MB each at the S2 shape) become 8-row gathers
+  bf16_t *qkv0_tab = nullptr, *qkv0_pre = nullptr;
+  bool qkv0_tried = false;
   bool trace = false, use_graph = true, ignore_eos = false;
   int max_top_k = 0;  // largest top_k over the LIVE slots (selects the sampler variant the graphs embed)
   std::vector<int> slot_top_k;  // per slot, 0 = released
@@ -284,12 +289,13 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
 }
 
 int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int pos, const int32_t* row_slot,
-               hipStream_t s, bool kv_only = false) {
+               hipStream_t s, bool kv_only = false, const bf16_t* qkv_pre = nullptr) {
   const Dims& d = h->fast;
   Workspace& ws = h->ws;
-  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
+  if (!qkv_pre)
+    FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
   FastAttnArgs a{};
-  a.qkv = ws.qkv; a.out = ws.ao; a.kc = h->fkc[layer]; a.vc = h->fvc[layer];
+  a.qkv = qkv_pre ? qkv_pre : ws.qkv; a.out = ws.ao; a.kc = h->fkc[layer]; a.vc = h->fvc[layer];
   a.qnw = h->cfg.fast_attention_qk_norm ? w.q_norm : nullptr;
   a.knw = h->cfg.fast_attention_qk_norm ? w.k_norm : nullptr;
   a.rope = h->fast_rope; a.row_slot = row_slot; a.B = B; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
@@ -326,6 +332,8 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   sa.row_slot = row_slot; sa.st = h->st; sa.mode = 0; sa.cb = 0; sa.sem_begin = c.semantic_begin_id;
   sa.sem_end = c.semantic_end_id; sa.im_end = h->ignore_eos ? -1 : c.im_end_id; sa.cbs = c.codebook_size; sa.fast_emb = h->fast_emb;
   sa.xf = h->xf; sa.fdim = c.fast_dim; sa.small_k = h->max_top_k <= 64;
+  const bool tab = h->qkv0_tab != nullptr && !h->trace;
+  sa.qkv0_tab = tab ? h->qkv0_tab : nullptr; sa.qkv0_out = h->qkv0_pre; sa.qkv0_dim = h->fast.qkv;
   FMI_CHECK(launch_sample(sa, s));
   h->launches += 1;
   // fast step 0 on the hidden state; its logits are discarded (inference.py:148-149)
@@ -337,7 +345,8 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   for (int i = 0; i < c.n_fast_layer; ++i)
     FMI_CHECK(block_fast(h, h->FL[i], i, f0, B, 0, row_slot, s, i == c.n_fast_layer - 1));
   for (int cb = 1; cb < c.num_codebooks; ++cb) {
-    for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, B, cb, row_slot, s));
+    for (int i = 0; i < c.n_fast_layer; ++i)
+      FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, B, cb, row_slot, s, false, (i == 0 && tab) ? h->qkv0_pre : nullptr));
     FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, B,
                      c.codebook_size, c.fast_dim, EPI_STORE, s, h->q_fast_out, h->s_fast_out));
     if (h->trace) {
@@ -370,6 +379,30 @@ int decode_frame(fmi_dualar* h, int B, hipStream_t s, bool head_only = false) {
   if (head_only) return tail_head(h, h->ws.x, B, s);
   FMI_CHECK(tail(h, h->ws.x, B, h->ws.row_slot, s));
   h->frame_launches = h->launches;
+  return FMI_OK;
+}
+
+// Tabulate fast layer 0's wqkv(rmsnorm(fast_embeddings[code])) for every code, 8 codes per launch of the decode
+// GEMV itself (its row results do not depend on the batch they are computed in, tests/test_dualar_gpu.py).
+int ensure_qkv0_table(fmi_dualar* h) {
+  if (h->qkv0_tried || !h->ready || h->max_batch == 0) return FMI_OK;
+  h->qkv0_tried = true;
+  static const bool off = []() { const char* e = getenv("FMI_NO_QKV0"); return e && atoi(e) != 0; }();
+  const fmi_dualar_config& c = h->cfg;
+  if (off || c.n_fast_layer < 1 || c.codebook_size % 8 != 0) return FMI_OK;
+  const Dims& d = h->fast;
+  const LayerW& w = h->FL[0];
+  FMI_CHECK(dev_alloc(&h->qkv0_tab, (int64_t)c.codebook_size * d.qkv));
+  FMI_CHECK(dev_alloc(&h->qkv0_pre, (int64_t)h->max_batch * d.qkv));
+  FMI_CHECK_HIP(hipDeviceSynchronize());   // dev_alloc clears on the null stream; h->stream does not wait for it
+  hipStream_t s = h->stream;
+  const int saved = h->launches;
+  for (int code = 0; code < c.codebook_size; code += 8)
+    FMI_CHECK(linear(h, h->fast_emb + (int64_t)code * d.dim, d.dim, w.wqkv, w.attn_norm, nullptr, 0,
+                     h->qkv0_tab + (int64_t)code * d.qkv, d.qkv, 8, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
+  h->launches = saved;
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  drop_graphs(h);
   return FMI_OK;
 }
 
@@ -483,7 +516,8 @@ void fmi_dualar_destroy(fmi_dualar* h) {
   for (auto p : h->fvc) hipFree(p);
   void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
                   h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
-                  h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging, h->staging2};
+                  h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging, h->staging2,
+                  h->qkv0_tab, h->qkv0_pre};
   for (void* p : ptrs)
     if (p) hipFree(p);
   hipEventDestroy(h->ev_in);
@@ -758,6 +792,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
                         const int32_t* max_new, const fmi_sampling* samp, int frame_index, hipStream_t s,
                         bool head_only = false) {
   const fmi_dualar_config& c = h->cfg;
+  FMI_CHECK(ensure_qkv0_table(h));
   int rows = 0;
   for (int i = 0; i < n; ++i) {
     FMI_CHECK(check_slot(h, slot_ids[i]));
@@ -919,6 +954,7 @@ int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int po
     FMI_CHECK(prefill_impl(h, 1, &slot, x_dev, &len, &mn, &sp, frame_index, s));
   } else {
     FMI_REQUIRE(pos0 < h->max_seq, "position %d beyond max_seq_len %d", pos0, h->max_seq);
+    FMI_CHECK(ensure_qkv0_table(h));
     FMI_CHECK(reserve_pages(h, slot, h->max_seq));
     FMI_CHECK(set_slot(h, slot, pos0, frame_index, h->max_seq, sp, false));
     FMI_CHECK_HIP(hipMemcpyAsync(h->st.cur + (int64_t)slot * ncb1, x_dev, ncb1 * 4, hipMemcpyDeviceToDevice, s));

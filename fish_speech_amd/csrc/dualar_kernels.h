@@ -93,12 +93,15 @@ struct AttnArgs {
   const int32_t* block_table;
   const int32_t* slot_pos;
   const int32_t* slot_done;   // decode only: a finished slot (SlotState.done != 0) no longer appends K/V
+  const int4* qtiles;         // prefill (MFMA kernel): per 16-row query tile {row0, rows, slot, first position}
+  int n_qtiles;
   int max_pages;
   int rows, H, KVH, D;
   float eps;
 };
 int launch_attn_prep(const AttnArgs& a, hipStream_t s);
-int launch_attn(const AttnArgs& a, hipStream_t s);
+int launch_attn(const AttnArgs& a, hipStream_t s);               // VALU kernel (kept for A/B parity runs)
+int launch_attn_prefill_mfma(const AttnArgs& a, hipStream_t s);  // MFMA flash attention over the query tiles
 int launch_attn_decode_fused(const AttnArgs& a, hipStream_t s);  // one row per slot only
 
 struct FastAttnArgs {
@@ -127,6 +130,11 @@ struct SampleArgs {
   const bf16_t* fast_emb; // [cbs][fdim] gathered into xf after the draw
   bf16_t* xf;             // [B][fdim]
   int fdim;
+  // first fast layer's wqkv(rmsnorm(fast_emb[code])) precomputed per code (a pure function of the code): the row of
+  // the drawn code is gathered next to the embedding, so the next fast position skips that GEMV
+  const bf16_t* qkv0_tab; // [cbs][qkv0_dim] or nullptr
+  bf16_t* qkv0_out;       // [B][qkv0_dim]
+  int qkv0_dim;
   // mode 2 (op-level): explicit parameters
   float temperature, top_p;
   int top_k;

@@ -198,7 +198,12 @@ __global__ void embed_kernel(EmbedArgs a) {
 }
 
 int launch_embed(const EmbedArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel, dim3(a.rows), dim3(256), 0, s, a);
+  // one thread per 8-element chunk of the row when that fits a work-group: every row request of the gather is in
+  // flight at once (dim 2560 = 320 chunks took two dependent trips with 256 threads)
+  const int chunks = a.dim / 8;
+  static const int env_t = []() { const char* e = getenv("FMI_EMBED_T"); return e ? atoi(e) : 0; }();
+  const int threads = env_t > 0 ? env_t : (chunks <= 1024 ? ((chunks + 63) / 64) * 64 : 256);
+  hipLaunchKernelGGL(embed_kernel, dim3(a.rows), dim3(threads), 0, s, a);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -994,6 +999,213 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
   }
 }
 
+// =====================================================================================
+// prefill attention on MFMA with LDS-staged K/V tiles (llama.py:910-934, MATH-backend numerics: fp32 scores,
+// fp32 softmax, fp32 accumulation, one bf16 rounding of the output)
+// =====================================================================================
+//
+// grid (query tiles, KVH), G waves (G = n_head / n_local_heads <= 4): the work-group owns 16 consecutive query rows
+// of one utterance and one kv head; wave w serves query head kvh*G + w, so all waves share the same K/V tiles.
+// Keys come in blocks of 32 (a block never straddles a 64-token KV page).  Per block:
+//   stage   K block -> s_k [32 keys][D] (row-major, 16-byte pad), V block -> s_vt TRANSPOSED [d][32 keys]
+//           (two keys per thread packed into one dword; rows permuted j*(D/8+1)+dchunk so the eight transposing
+//           stores of a thread's 8 d-values are bank-conflict free); the next block's global loads are issued
+//           before the maths of the current one (register prefetch);
+//   scores  S^T = K Q^T with v_mfma_f32_16x16x32_bf16: A = K rows (16 keys x 32 d, ds_read_b128), B = Q^T held in
+//           registers for the whole kernel; a lane then holds, for ITS query column, 8 of the 32 keys -- which is
+//           exactly a B-operand fragment of the next MFMA if the key order inside the block is permuted the same
+//           way for V (so the probabilities never leave registers: no LDS round trip, no shuffles);
+//   softmax online, fp32, per query column (reductions over the 4 lane groups by two xor-shuffles);
+//   output  O^T += V^T P^T: A = V^T (16 d x 32 keys from s_vt, two ds_read_b64), B = P split into bf16 hi + lo
+//           halves (two MFMAs: the weights keep ~16 significant bits, the reference multiplies fp32 weights).
+// Causal tiles are skipped (key blocks beyond the tile's last position are never visited), the diagonal block is
+// masked by select.  Tile descriptors (row0, rows, slot, first position) come from the host, heaviest first.
+template <int D, int G>
+__global__ __launch_bounds__(64 * G) void attn_prefill_mfma_kernel(AttnArgs a) {
+  constexpr int KB = 32, NT = 64 * G, DC = D / 8;
+  constexpr int KROW = D + 8;                 // bf16 elements per s_k row (+16 bytes)
+  constexpr int VROWB = KB * 2 + 8;           // bytes per s_vt row (32 keys + 8 bytes pad)
+  constexpr int VROWS = 8 * (DC + 1);         // permuted row index j*(DC+1) + dchunk
+  constexpr int KCH = KB * DC / NT > 0 ? KB * DC / NT : 1;        // 16-byte K chunks per thread
+  constexpr int VCH = (KB / 2) * DC / NT > 0 ? (KB / 2) * DC / NT : 1;  // key-pair chunks per thread
+  static_assert((KB * DC) % NT == 0 || KB * DC < NT, "K staging");
+  __shared__ __attribute__((aligned(16))) bf16_t s_k[KB * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char s_vt[VROWS * VROWB];
+
+  const int4 td = a.qtiles[blockIdx.x];  // x row0, y rows (1..16), z slot, w first position
+  const int kvh = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int H = a.H, KVH = a.KVH;
+  const int head = kvh * G + wave;
+  const int32_t* bt = a.block_table + (int64_t)td.z * a.max_pages;
+  const int last_pos = td.w + td.y - 1;
+  const int n_blocks = last_pos / KB + 1;
+  const int qpos = td.w + c;
+
+  // Q^T fragments (B operand: column = query c, k rows = d chunk g of k-step kk)
+  bf16x8 qf[D / 32];
+  {
+    const int qrow = td.x + (c < td.y ? c : td.y - 1);
+    const bf16_t* qp = a.q + ((int64_t)qrow * H + head) * D + g * 8;
+#pragma unroll
+    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32);
+  }
+
+  f32x4 o[D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -1e30f, l = 0.f;
+  const float scale = 1.0f / sqrtf((float)D);
+
+  // ---- staging helpers: K chunk i -> (key i / DC, dchunk i % DC); V chunk i -> (key pair i / DC, dchunk i % DC)
+  uint4 kreg[KCH], vreg[VCH][2];
+  auto fetch = [&](int kb) {
+    const int page = bt[(kb * KB) / KV_PAGE];
+    const int64_t pbase = ((int64_t)page * KVH + kvh) * KV_PAGE + (kb * KB) % KV_PAGE;
+#pragma unroll
+    for (int it = 0; it < KCH; ++it) {
+      const int i = tid + it * NT;
+      if (i < KB * DC) {
+        const int key = i / DC, dc = i % DC;
+        kreg[it] = *reinterpret_cast<const uint4*>(a.kpool + (pbase + key) * D + dc * 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < VCH; ++it) {
+      const int i = tid + it * NT;
+      if (i < (KB / 2) * DC) {
+        const int kp = i / DC, dc = i % DC;
+        const bool v0 = kb * KB + 2 * kp <= last_pos, v1 = kb * KB + 2 * kp + 1 <= last_pos;
+        // rows beyond the tile's last position have not been written (stale pool contents): they must read as 0,
+        // a masked probability of 0 times a stale NaN/Inf would poison the accumulator
+        vreg[it][0] = v0 ? *reinterpret_cast<const uint4*>(a.vpool + (pbase + 2 * kp) * D + dc * 8) : make_uint4(0, 0, 0, 0);
+        vreg[it][1] = v1 ? *reinterpret_cast<const uint4*>(a.vpool + (pbase + 2 * kp + 1) * D + dc * 8) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < KCH; ++it) {
+      const int i = tid + it * NT;
+      if (i < KB * DC) *reinterpret_cast<uint4*>(&s_k[(i / DC) * KROW + (i % DC) * 8]) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VCH; ++it) {
+      const int i = tid + it * NT;
+      if (i < (KB / 2) * DC) {
+        const int kp = i / DC, dc = i % DC;
+        const bf16_t* e0 = reinterpret_cast<const bf16_t*>(&vreg[it][0]);
+        const bf16_t* e1 = reinterpret_cast<const bf16_t*>(&vreg[it][1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          *reinterpret_cast<uint32_t*>(&s_vt[(j * (DC + 1) + dc) * VROWB + kp * 4]) = (uint32_t)e0[j] | ((uint32_t)e1[j] << 16);
+      }
+    }
+  };
+
+  fetch(0);
+  for (int kb = 0; kb < n_blocks; ++kb) {
+    __syncthreads();          // every wave is done reading the previous block's tiles
+    stage();
+    __syncthreads();
+    if (kb + 1 < n_blocks) fetch(kb + 1);
+
+    // ---- scores: two 16-key tiles, lane (c, g) ends up with keys kt*16 + g*4 + j of query column c
+    f32x4 sacc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      sacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < D / 32; ++kk) {
+        const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(&s_k[(kt * 16 + c) * KROW + kk * 32 + g * 8]);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[kk], sacc[kt], 0, 0, 0);
+      }
+    }
+    float sc[8];
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kb * KB + kt * 16 + g * 4 + j;
+        const float v = key <= qpos ? sacc[kt][j] * scale : -1e30f;
+        sc[kt * 4 + j] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float corr = __expf(m - mn);
+    float ps = 0.f, pr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pr[j] = sc[j] > -1e29f ? __expf(sc[j] - mn) : 0.f;
+      ps += pr[j];
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * corr + ps;
+    m = mn;
+    // probabilities as the B operand (k slots g*8 + jj = keys {g*4 + jj | jj < 4} and {16 + g*4 + jj - 4}), hi + lo
+    bf16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16_t hi = f2bf(pr[j]);
+      ph[j] = (short)hi;
+      pl[j] = (short)f2bf(pr[j] - bf2f(hi));
+    }
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+      const int d = dt * 16 + c;
+      const unsigned char* row = &s_vt[((d & 7) * (DC + 1) + (d >> 3)) * VROWB];
+      const uint2 lo = *reinterpret_cast<const uint2*>(row + g * 8);        // keys g*4 .. g*4+3
+      const uint2 hi = *reinterpret_cast<const uint2*>(row + 32 + g * 8);   // keys 16 + g*4 ..
+      u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+      const bf16x8 vfrag = *reinterpret_cast<bf16x8*>(&av);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] *= corr;
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, ph, o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pl, o[dt], 0, 0, 0);
+    }
+  }
+
+  if (c < td.y) {   // lane holds query column c, output dims dt*16 + g*4 + j
+    const float inv = 1.0f / l;
+    bf16_t* op = a.out + ((int64_t)(td.x + c) * H + head) * D + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+      const uint32_t w0 = (uint32_t)f2bf(o[dt][0] * inv) | ((uint32_t)f2bf(o[dt][1] * inv) << 16);
+      const uint32_t w1 = (uint32_t)f2bf(o[dt][2] * inv) | ((uint32_t)f2bf(o[dt][3] * inv) << 16);
+      *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(w0, w1);
+    }
+  }
+}
+
+template <int D>
+static int launch_attn_prefill_d(const AttnArgs& a, hipStream_t s) {
+  const int G = a.H / a.KVH;
+  dim3 grid(a.n_qtiles, a.KVH);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, 1>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, 2>), grid, dim3(128), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, 4>), grid, dim3(256), 0, s, a); break;
+    default: return set_error(FMI_EINVAL, "attn: GQA ratio %d unsupported", G);
+  }
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+int launch_attn_prefill_mfma(const AttnArgs& a, hipStream_t s) {
+  FMI_REQUIRE(a.H % a.KVH == 0 && a.qtiles && a.n_qtiles > 0, "attn_prefill_mfma: bad arguments");
+  switch (a.D) {
+    case 32: return launch_attn_prefill_d<32>(a, s);
+    case 64: return launch_attn_prefill_d<64>(a, s);
+    case 128: return launch_attn_prefill_d<128>(a, s);
+    default: return set_error(FMI_EINVAL, "attn: head_dim %d unsupported (32/64/128)", a.D);
+  }
+}
+
 // Decode-time fusion of attn_prep + attn (one row per utterance, so a work-group only ever needs the
 // K/V of its own (slot, kv-head) -- no cross-work-group dependency).  grid (B, KVH), 8 waves.
 //   phase 1: k head (norm+RoPE -> cache + LDS), v head (-> cache + LDS), G q heads (norm+RoPE -> LDS)
@@ -1660,6 +1872,11 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const bf16_t* src = a.fast_emb + (int64_t)tok * a.fdim;
     for (int c = tid * 8; c < a.fdim; c += 256 * 8)
       *reinterpret_cast<uint4*>(a.xf + (int64_t)b * a.fdim + c) = *reinterpret_cast<const uint4*>(src + c);
+    if (a.qkv0_tab) {  // first fast layer's q|k|v of the drawn code (see SampleArgs)
+      const bf16_t* q = a.qkv0_tab + (int64_t)tok * a.qkv0_dim;
+      for (int c = tid * 8; c < a.qkv0_dim; c += 256 * 8)
+        *reinterpret_cast<uint4*>(a.qkv0_out + (int64_t)b * a.qkv0_dim + c) = *reinterpret_cast<const uint4*>(q + c);
+    }
   }
   // frame bookkeeping after the last codebook (decode_n_tokens, inference.py:224-233)
   if (a.mode == 1 && a.cb == a.st.ncb1 - 2) {
@@ -1987,6 +2204,11 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     const bf16_t* src = a.fast_emb + (int64_t)tok * a.fdim;
     for (int c = lane * 8; c < a.fdim; c += 64 * 8)
       *reinterpret_cast<uint4*>(a.xf + (int64_t)b * a.fdim + c) = *reinterpret_cast<const uint4*>(src + c);
+    if (a.qkv0_tab) {  // ... and the first fast layer's q|k|v of that code (precomputed with the very same GEMV)
+      const bf16_t* q = a.qkv0_tab + (int64_t)tok * a.qkv0_dim;
+      for (int c = lane * 8; c < a.qkv0_dim; c += 64 * 8)
+        *reinterpret_cast<uint4*>(a.qkv0_out + (int64_t)b * a.qkv0_dim + c) = *reinterpret_cast<const uint4*>(q + c);
+    }
   }
   if (a.mode == 1 && a.cb == a.st.ncb1 - 2 && lane == 0) {  // frame bookkeeping, as in sample_kernel
     const int ncb1 = a.st.ncb1;

@@ -95,7 +95,7 @@ def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float
     ref_hidden = bf16_from_u16(z["hidden"])
     ref_fast = bf16_from_u16(z["fast_logits"])
     window = torch.zeros(ncb1, 10, dtype=torch.int32)
-    stats = dict(frames=0, decisions=0, exact=0, max_ulp_slow=0.0, max_ulp_fast=0.0, max_rel_l2=0.0)
+    stats = dict(frames=0, decisions=0, exact=0, max_ulp_slow=0.0, max_ulp_fast=0.0, max_rel_l2=0.0, miss_margins=[])
 
     def ulp_err(a, b):
         a, b = a.float().cpu(), b.float().cpu()
@@ -109,6 +109,8 @@ def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float
     def near_argmax(ref_logits, picked_idx, ref_idx):
         lf = ref_logits.float()
         top = lf.max()
+        if picked_idx != ref_idx:   # how far below the reference's maximum the picked token sits, in bf16 steps
+            stats["miss_margins"].append(round(float((top - lf[picked_idx]) / O.bf16_ulp(top)), 2))
         return float(lf[picked_idx]) >= float(top - decide_ulps * O.bf16_ulp(top)) or picked_idx == ref_idx
 
     n_frames = seq.shape[1] - T
