@@ -7,6 +7,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <set>
 #include <string>
@@ -34,6 +35,8 @@ struct Workspace {
   int rows = 0;
   bf16_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *ao = nullptr, *act = nullptr;
   int32_t *row_slot = nullptr, *row_pos = nullptr, *last_rows = nullptr;
+  int4* qtiles = nullptr;   // prefill attention: 16-row query tiles {row0, rows, slot, first position}
+  int n_qtiles = 0;
 };
 
 }  // namespace
@@ -72,6 +75,7 @@ struct fmi_dualar {
   bf16_t *qkv0_tab = nullptr, *qkv0_pre = nullptr;
   bool qkv0_tried = false;
   bool trace = false, use_graph = true, ignore_eos = false;
+  int attn_impl = 1;   // prefill attention: 1 = MFMA flash kernel with LDS-staged K/V tiles, 0 = VALU kernel (A/B parity)
   int max_top_k = 0;  // largest top_k over the LIVE slots (selects the sampler variant the graphs embed)
   std::vector<int> slot_top_k;  // per slot, 0 = released
   std::map<int, hipGraphExec_t> graphs;
@@ -204,7 +208,7 @@ int dev_alloc(T** p, int64_t n) {
 }
 
 int free_ws(Workspace& w) {
-  void* ptrs[] = {w.x, w.xn, w.qkv, w.q, w.ao, w.act, w.row_slot, w.row_pos, w.last_rows};
+  void* ptrs[] = {w.x, w.xn, w.qkv, w.q, w.ao, w.act, w.row_slot, w.row_pos, w.last_rows, w.qtiles};
   for (void* p : ptrs)
     if (p) hipFree(p);
   w = Workspace();
@@ -235,6 +239,7 @@ int ensure_rows(fmi_dualar* h, int rows) {
   FMI_CHECK(dev_alloc(&w.row_slot, rows));
   FMI_CHECK(dev_alloc(&w.row_pos, rows));
   FMI_CHECK(dev_alloc(&w.last_rows, std::max(rows, 1)));
+  FMI_CHECK(dev_alloc(&w.qtiles, (int64_t)rows / 16 + h->max_batch + 1));
   w.rows = rows;
   return FMI_OK;
 }
@@ -279,7 +284,9 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
     h->launches += 1;
   } else {
     FMI_CHECK(launch_attn_prep(a, s));
-    FMI_CHECK(launch_attn(a, s));
+    a.qtiles = ws.qtiles; a.n_qtiles = ws.n_qtiles;
+    if (h->attn_impl == 1 && ws.n_qtiles > 0) FMI_CHECK(launch_attn_prefill_mfma(a, s));
+    else FMI_CHECK(launch_attn(a, s));
     h->launches += 2;
   }
   FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo));
@@ -803,6 +810,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
   }
   FMI_CHECK(ensure_rows(h, std::max(rows, h->max_batch)));
   std::vector<int32_t> row_slot(rows), row_pos(rows), last(n), slots(n);
+  std::vector<int4> tiles;
   int r = 0;
   for (int i = 0; i < n; ++i) {
     int mn = max_new[i];
@@ -813,6 +821,8 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
     // stops appending once SlotState.done is set)
     FMI_CHECK(reserve_pages(h, slot_ids[i], std::min(std::max(limit, lens[i]) + 1, h->max_seq)));
     FMI_CHECK(set_slot(h, slot_ids[i], lens[i], frame_index, limit, samp[i], frame_index == 0));
+    for (int t0 = 0; t0 < lens[i]; t0 += 16)
+      tiles.push_back(make_int4(r + t0, std::min(16, lens[i] - t0), slot_ids[i], t0));
     for (int t = 0; t < lens[i]; ++t, ++r) {
       row_slot[r] = slot_ids[i];
       row_pos[r] = t;
@@ -824,6 +834,10 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
   FMI_CHECK_HIP(hipMemcpyAsync(ws.row_slot, row_slot.data(), rows * 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipMemcpyAsync(ws.row_pos, row_pos.data(), rows * 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipMemcpyAsync(ws.last_rows, last.data(), n * 4, hipMemcpyHostToDevice, s));
+  // causal work grows with the tile's position: heaviest query tiles first
+  std::stable_sort(tiles.begin(), tiles.end(), [](const int4& x, const int4& y) { return x.w > y.w; });
+  ws.n_qtiles = (int)tiles.size();
+  FMI_CHECK_HIP(hipMemcpyAsync(ws.qtiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
   h->launches = 0;
   EmbedArgs e{};
@@ -1060,6 +1074,13 @@ int fmi_dualar_set_ignore_eos(fmi_dualar* h, int enable) {
     drop_graphs(h);
   }
   h->ignore_eos = enable != 0;
+  return FMI_OK;
+}
+
+int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_REQUIRE(impl == 0 || impl == 1, "attn impl must be 0 (VALU) or 1 (MFMA)");
+  h->attn_impl = impl;
   return FMI_OK;
 }
 

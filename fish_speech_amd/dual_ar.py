@@ -470,6 +470,10 @@ class MiDualAR:
     def set_graph(self, enable: bool):
         check(self.lib.fmi_dualar_set_graph(self._h, int(enable)))
 
+    def set_attn_impl(self, impl: int):
+        """Prefill attention kernel: 1 = MFMA flash attention (default), 0 = VALU kernel (A/B parity runs)."""
+        check(self.lib.fmi_dualar_set_attn_impl(self._h, int(impl)))
+
     def set_ignore_eos(self, enable: bool):
         """Keep generating past <|im_end|> (fixed-length synthetic benchmarks)."""
         check(self.lib.fmi_dualar_set_ignore_eos(self._h, int(enable)))

@@ -155,6 +155,9 @@ int fmi_dualar_set_trace(fmi_dualar* h, int enable, void** fast_trace);
 int fmi_dualar_set_ignore_eos(fmi_dualar* h, int enable);
 /* Disable hipGraph replay (eager launches) -- used by tests/profiling. */
 int fmi_dualar_set_graph(fmi_dualar* h, int enable);
+/* Prefill attention implementation (F.scaled_dot_product_attention, llama.py:928-934): 1 = MFMA flash attention with
+ * LDS-staged K/V tiles (default), 0 = the VALU kernel of round 1 (kept for A/B parity runs). */
+int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl);
 /* Time of the last fmi_dualar_decode in ms measured with HIP events on `stream`, and the
  * number of kernel launches per frame. */
 int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_frame);

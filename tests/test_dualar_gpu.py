@@ -882,3 +882,68 @@ def test_decode_one_token_accepts_only_the_generate_bias():
     bad[0, 0, cfg.semantic_begin_id + 3] = -5.0
     with pytest.raises(NotImplementedError):
         decode_one_token(model, x, pos, t, t, 1, semantic_logit_bias=bad)
+
+
+# ------------------------------------------------------------------------------- MFMA flash-attention prefill
+
+
+def _long_cfg(kind, max_seq):
+    from oracle.search_golden import MID
+
+    kw = dict(MID) if kind == "mid" else {}
+    kw["max_seq_len"] = max_seq
+    return O.DualARConfig(**kw)
+
+
+@pytest.mark.parametrize("kind,T", [("mid", 200), ("mid", 1024), ("mid", 2048), ("tiny", 333), ("tiny", 17)])
+def test_mfma_flash_attention_prefill_vs_oracle_and_valu_kernel(kind, T):
+    """Prefill attention on MFMA with LDS-staged K/V tiles (llama.py:910-934) at T = 200, 1024 and 2048 (head_dim 128,
+    4 query heads per kv head: the S2 geometry) and at head_dim 32 / 2 heads per kv head, voice-clone shaped prompts
+    (semantic tail with codes): logits and hidden state of the last position against the CPU oracle (relative L2
+    <= 2 %, the bf16 noise bound of the other parity tests) and against the round-1 VALU kernel run on the same
+    cache (<= 1 %: both are fp32-softmax kernels, only the summation order and the bf16 hi+lo split of the
+    probabilities differ)."""
+    cfg = _long_cfg(kind, 2304 if T > 400 else 512)
+    state = O.make_synthetic_state(cfg, seed=5, head_gain=8.0)
+    model = _make_model(cfg, state, max_batch=1)
+    orc = O.DualAROracle(cfg, state)
+    orc.setup_caches(1, cfg.max_seq_len)
+    p = O.make_prompt(cfg, T, seed=T, n_semantic=T // 2)
+    ncb1 = cfg.num_codebooks + 1
+    x, pos = p.view(1, ncb1, -1), torch.arange(T)
+    want_logits, want_hidden = orc.forward_generate(x, pos, math_backend=True)
+    ids = model._table(1, torch.int32).view(-1).long().cpu()
+    out = {}
+    for impl in (1, 0):
+        model.set_attn_impl(impl)
+        r = model.forward_generate(x.to(DEV), pos.to(DEV))
+        out[impl] = (r.logits[0, 0].float().cpu()[ids], r.hidden_states.float().cpu().view(-1))
+    model.set_attn_impl(1)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    wl, wh = want_logits[0, 0].float()[ids], want_hidden.float().view(-1)
+    e = dict(mfma_vs_oracle=(rel(out[1][0], wl), rel(out[1][1], wh)), valu_vs_oracle=(rel(out[0][0], wl), rel(out[0][1], wh)),
+             mfma_vs_valu=(rel(out[1][0], out[0][0]), rel(out[1][1], out[0][1])))
+    print(kind, T, e)
+    assert max(e["mfma_vs_oracle"]) <= 2e-2, e
+    assert max(e["mfma_vs_valu"]) <= 1e-2, e
+    assert max(e["mfma_vs_oracle"]) <= 1.5 * max(e["valu_vs_oracle"]) + 4e-3, e   # a bf16 step or two of either
+
+
+def test_mfma_flash_attention_ragged_batch_equals_single_prompts():
+    """Query tiles of different utterances (lengths 1, 16, 17, 130, 47: full tiles, one-row tiles, padded tiles) in
+    one prefill: every utterance's prefill-frame logits equal those of its own batch-1 prefill bit for bit (a tile
+    only ever reads its own slot's pages), and the first frame's tokens agree."""
+    cfg, state, _ = load_dualar_case("mid_peaky")
+    model = _make_model(cfg, state, max_batch=5)
+    lens = [1, 16, 17, 130, 47]
+    prompts = [O.make_prompt(cfg, T, seed=40 + i, n_semantic=T // 3) for i, T in enumerate(lens)]
+    samp = [model._sampling(0.7, 0.7, 1, 9, True) for _ in lens]
+    model.prefill(list(range(5)), prompts, [4] * 5, samp)
+    logits, _, hidden, _ = model.debug_taps(5)
+    for i in range(5):
+        model.release(i)
+    for i, p in enumerate(prompts):
+        model.prefill([0], [p], [4], [samp[i]])
+        l1, _, h1, _ = model.debug_taps(1)
+        model.release(0)
+        assert torch.equal(l1[0], logits[i]) and torch.equal(h1[0], hidden[i]), i
