@@ -112,6 +112,11 @@ struct fmi_dac {
   size_t staging_bytes = 0;
   float* last_z = nullptr;
   int last_zC = 0, last_zL = 0;
+  // decode-side contraction arithmetic (ConvArgs::planes): 3 = bf16 matrix cores on 3-plane splits (fp32-class,
+  // default), 0 = fp32 matrix cores, 2 / 1 = fewer planes.  The encoder always runs on the fp32 matrix cores.
+  int decode_planes = 3;
+  int cur_planes = 0;
+  std::vector<ConvW> plane_jobs;
 };
 
 namespace {
@@ -139,6 +144,13 @@ int validate(const fmi_dac_config& c) {
 struct Builder {
   fmi_dac* h;
   int64_t off = 0;
+  bool planes = false;   // also reserve the bf16 hi/mid/lo planes of the convs built from here on (decode side)
+  void add_planes(Conv& c) {
+    if (!planes) return;
+    c.w.cin_pad16 = (int)align_up(c.w.cin, 16);
+    c.w.wb = (const bf16_t*)take((int64_t)c.w.phases * c.w.taps * c.w.cin_pad16 * c.w.cout_pad * 3, 2);
+    h->plane_jobs.push_back(c.w);
+  }
   float* take(int64_t elems, int esize = 4) {
     float* p = h->arena ? (float*)(h->arena + off) : nullptr;
     off = align_up(off + elems * esize, 256);
@@ -174,6 +186,7 @@ struct Builder {
     s.cout_pad = c.w.cout_pad; s.cin_pad = c.w.cin_pad; s.stride = stride;
     h->reg[prefix + ".weight"] = s;
     if (bias) c.w.bias = raw(prefix + ".bias", {cout});
+    add_planes(c);
     return c;
   }
   // linear layer (k=1, no bias) whose rows come from `parts` checkpoint tensors stacked along cout
@@ -191,6 +204,7 @@ struct Builder {
       s.cout_pad = c.w.cout_pad; s.cin_pad = c.w.cin_pad; s.co_off = (int)i * cout_each;
       h->reg[names[i]] = s;
     }
+    add_planes(c);
     return c;
   }
   ResUnit res_unit(const std::string& p, int dim, int dil) {
@@ -250,6 +264,7 @@ int64_t build(fmi_dac* h) {
   const fmi_dac_config& c = h->cfg;
   Builder b{h};
   h->reg.clear();
+  h->plane_jobs.clear();
   h->enc.clear(); h->dec.clear(); h->rvq.clear();
   h->down_conv.clear(); h->up_conv.clear(); h->down_cnx.clear(); h->up_cnx.clear();
   const int L = c.latent_dim;
@@ -283,13 +298,16 @@ int64_t build(fmi_dac* h) {
     h->down_conv.push_back(b.conv(p + ".0.conv", L, L, c.downsample[i], c.downsample[i], 1, true, false));
     h->down_cnx.push_back(b.convnext(p + ".1", L));
   }
+  b.planes = true;   // everything built from here on runs in from_indices / decode
   for (int i = 0; i < 2; ++i) {
     const std::string p = "quantizer.upsample." + std::to_string(i);
     const int f = c.downsample[1 - i];
     h->up_conv.push_back(b.conv(p + ".0.conv", L, L, f, f, 1, true, true));
     h->up_cnx.push_back(b.convnext(p + ".1", L));
   }
+  b.planes = false;
   h->pre = b.transformer("quantizer.pre_module", L, c.tf_layers, c.tf_ffn, c.tf_window);
+  b.planes = true;
   h->post = b.transformer("quantizer.post_module", L, c.tf_layers, c.tf_ffn, c.tf_window);
   const int64_t lut_rows = c.semantic_codebook_size + (int64_t)c.n_codebooks * c.codebook_size;
   h->lut = b.take(lut_rows * L);
@@ -355,6 +373,7 @@ int run_conv(fmi_dac* h, const Conv& c, const float* x, float* out, int B, int l
   ConvArgs a{};
   a.w = c.w; a.x = x; a.out = out; a.snake_alpha = snake; a.res = res; a.gamma = gamma; a.B = B; a.lin = lin;
   a.act = act;
+  a.planes = c.w.wb ? h->cur_planes : 0;
   int lout;
   if (c.transposed) {  // CausalTransConvNet: (lin-1)*s + k - (k - s) = lin * s
     lout = lin * c.stride;
@@ -619,9 +638,20 @@ int fmi_dac_finalize_weights(fmi_dac* h, void* stream) {
     }
     FMI_CHECK_HIP(hipMemcpyAsync(h->rope, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, s));
   }
+  // bf16 hi/mid/lo planes of the decode-side weights (inside the arena: they travel with the broadcast)
+  for (const ConvW& w : h->plane_jobs)
+    FMI_CHECK(launch_split_conv_planes(w.w, const_cast<bf16_t*>(w.wb), w.phases * w.taps, w.cin_pad, w.cin_pad16,
+                                       w.cout_pad, s));
   FMI_CHECK_HIP(hipStreamSynchronize(s));
   h->ready = true;
   return sync_out(h, stream);
+}
+
+int fmi_dac_set_precision(fmi_dac* h, int planes) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_REQUIRE(planes >= 0 && planes <= 3, "planes must be 0 (fp32 matrix cores) or 1..3 (bf16 planes)");
+  h->decode_planes = planes;
+  return FMI_OK;
 }
 
 int fmi_dac_weights_ready(fmi_dac* h) {
@@ -635,6 +665,7 @@ int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_
   FMI_REQUIRE(h->ready, "codec weights not ready");
   FMI_REQUIRE(B >= 1 && T >= 1, "empty input");
   FMI_CHECK(sync_in(h, stream));
+  h->cur_planes = h->decode_planes;
   float *X, *Y;
   int len;
   FMI_CHECK(run_quantizer_decode(h, indices_dev, B, T, &X, &Y, &len));
@@ -651,6 +682,7 @@ int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, 
   const fmi_dac_config& c = h->cfg;
   const int L0 = c.latent_dim;
   FMI_CHECK(sync_in(h, stream));
+  h->cur_planes = h->decode_planes;
   hipStream_t s = h->stream;
   float *X, *Y;
   int len;
@@ -672,6 +704,7 @@ int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* a
   FMI_REQUIRE(B >= 1 && L >= 1, "empty input");
   const fmi_dac_config& c = h->cfg;
   FMI_CHECK(sync_in(h, stream));
+  h->cur_planes = h->decode_planes;
   // L latent frames = L/4 code frames worth of decoder work
   const int64_t peak = (int64_t)B * decode_peak_elems(c, cdiv(L, 4));
   FMI_CHECK(ensure_buf(h, 0, peak));
@@ -696,6 +729,7 @@ int fmi_dac_encode(fmi_dac* h, const float* audio_dev, int B, int N, int64_t* in
   const int fl = frame_length(c);
   FMI_REQUIRE(B >= 1 && N >= fl && N % fl == 0, "audio length %d must be a positive multiple of frame_length %d", N, fl);
   FMI_CHECK(sync_in(h, stream));
+  h->cur_planes = 0;   // encode: fp32 matrix cores (the codes are compared bit for bit with the reference's)
   hipStream_t s = h->stream;
   // peak activation: the block-1 residual units run at full rate on encoder_dim channels
   int64_t peak = (int64_t)c.encoder_dim * N;

@@ -16,6 +16,11 @@ struct ConvW {
   const float* bias = nullptr;  // [cout] or nullptr
   int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0;
   int phases = 1, taps = 1;
+  // the same weights as three bf16 planes hi/mid/lo with hi + mid + lo == w to 24 bits (launch_split_conv_planes):
+  //   wb[phase][tap][ci_pad16/16][plane][co_pad][16]   (16-byte halves of a [16] row swapped on rows with bit 3 set)
+  // operands of the bf16 matrix cores (conv_mfma_bf16_kernel); nullptr = this layer only has the fp32 path
+  const bf16_t* wb = nullptr;
+  int cin_pad16 = 0;
 };
 
 enum ConvAct { ACT_NONE = 0, ACT_GELU = 1 };
@@ -33,10 +38,19 @@ struct ConvArgs {
   int tap_base;         // input column of tap 0 for output column 0 (= -(left pad); 0 for transposed)
   int out_stride;       // output column step per computed column (1; stride for transposed)
   int act;
+  // arithmetic of the contraction: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32, an fmaf chain);
+  // 3 = bf16 matrix cores on three-plane splits of both operands, 6 partial products, fp32 accumulation
+  //     (fp32-class: drops only terms below 2^-24 of a product); 2 = two planes, 3 products (~2^-16);
+  // 1 = one plane (operands rounded to bf16: what torch.autocast(bfloat16) makes of a conv / linear)
+  int planes;
 };
 // out[b][co][q*out_stride + phase] = res + gamma * act(bias + sum_ci sum_tap w[phase][tap][ci][co] *
 //                                    snake(x)[b][ci][q*x_stride + tap_base + tap*tap_step])
 int launch_conv(const ConvArgs& a, hipStream_t s);
+
+// fp32 packed weights (layout above) -> the three bf16 planes of ConvW::wb
+int launch_split_conv_planes(const float* w_packed, bf16_t* wb, int tapgroups /*phases*taps*/, int cin_pad,
+                             int cin_pad16, int cout_pad, hipStream_t s);
 
 // weight re-layouts (run once at load)
 int launch_pack_conv(const float* w_src /*[cout][cin][k]*/, float* dst, int cout, int cin, int k, int cin_pad,

@@ -269,6 +269,287 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 1) ? 4 : (MT * NT <= 4 ? 3 :
     }
 }
 
+// =====================================================================================
+// the same implicit GEMM on the bf16 matrix cores, fp32-class through operand splitting
+// =====================================================================================
+//
+// gfx950's fp32-input MFMA runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md).  An fp32 value is the exact sum of three
+// bf16 pieces (8 + 8 + 8 significant bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)), so
+//   x * w = (xh + xm + xl)(wh + wm + wl) = xh wh + xh wm + xm wh + xm wm + xh wl + xl wh   (+ terms < 2^-24 |x w|)
+// is six v_mfma_f32_32x32x16_bf16 (exact bf16 products, fp32 accumulation) per 16 reduction steps: 6 x 32 cycles
+// against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same 16 steps -- 2.7x the matrix throughput at the accuracy
+// of fp32 arithmetic (the dropped terms are below the rounding of an fp32 product).  PLANES = 2 keeps three products
+// (~2^-16), PLANES = 1 one (operands rounded to bf16 = what torch.autocast(bfloat16) computes for conv / linear).
+//
+// Same tiling, LDS-DMA weight staging and epilogue as conv_mfma_kernel; a reduction group is 16 input channels per
+// plane, and the byte layout of one (tap, group, plane) weight tile / input tile equals the fp32 kernel's 8-channel
+// tile (32 bytes per row, 16-byte half per lane, same half swap), so the operand addressing carries over.
+__device__ inline uint32_t cvt_pk_bf16_f32(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// two fp32 values -> packed bf16 pairs of the three planes
+__device__ inline void split3_pk(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = cvt_pk_bf16_f32(x0, x1);
+  float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16_f32(r0, r1);
+  r0 -= __uint_as_float(m << 16);
+  r1 -= __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16_f32(r0, r1);
+}
+
+__host__ __device__ inline int64_t conv_wb_index(int tapg, int ci, int co, int plane, int cin_pad16, int cout_pad) {
+  return (((((int64_t)tapg * (cin_pad16 >> 4) + (ci >> 4)) * 3 + plane) * cout_pad + co) << 4) +
+         ((((ci >> 3) ^ (co >> 3)) & 1) << 3) + (ci & 7);
+}
+
+__global__ void split_conv_planes_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, int tapgroups,
+                                         int cin_pad, int cin_pad16, int cout_pad) {
+  const int64_t total = (int64_t)tapgroups * (cin_pad16 >> 1) * cout_pad;   // one thread per channel PAIR
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % cout_pad);
+    const int cp = (int)((i / cout_pad) % (cin_pad16 >> 1));
+    const int tg = (int)(i / ((int64_t)cout_pad * (cin_pad16 >> 1)));
+    const int ci = cp * 2;
+    const float x0 = ci < cin_pad ? w[conv_w_index(tg, ci, co, cin_pad, cout_pad)] : 0.f;
+    const float x1 = ci + 1 < cin_pad ? w[conv_w_index(tg, ci + 1, co, cin_pad, cout_pad)] : 0.f;
+    uint32_t h, m, l;
+    split3_pk(x0, x1, h, m, l);
+    *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 0, cin_pad16, cout_pad)) = h;
+    *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 1, cin_pad16, cout_pad)) = m;
+    *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 2, cin_pad16, cout_pad)) = l;
+  }
+}
+
+int launch_split_conv_planes(const float* w_packed, bf16_t* wb, int tapgroups, int cin_pad, int cin_pad16, int cout_pad,
+                             hipStream_t s) {
+  FMI_REQUIRE(cin_pad16 % 16 == 0 && cin_pad16 >= cin_pad && cout_pad % 32 == 0, "split planes: bad padding");
+  hipLaunchKernelGGL(split_conv_planes_kernel, dim3(2048), dim3(256), 0, s, w_packed, wb, tapgroups, cin_pad, cin_pad16,
+                     cout_pad);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+template <int MT, int NT, int G, int NP, int TAPS>
+__global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
+  const int taps = TAPS > 0 ? TAPS : a.w.taps;            // TAPS = 7: the tap loop is unrolled (operand reads of the
+  char* Ws = reinterpret_cast<char*>(smem);                 // next tap overlap the MFMAs of the current one)
+  const int nw_bytes = taps * G * NP * CO_T * 32;
+  char* Xs = Ws + nw_bytes;                                 // [G][NP][wx] columns of 32 bytes
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int q0 = blockIdx.x * TT;
+  const int co0 = blockIdx.y * CO_T;
+  const int b = blockIdx.z / a.w.phases, phase = blockIdx.z % a.w.phases;
+  const int c0 = q0 * a.x_stride + a.tap_base - tap_off0;
+  const float* xb = a.x + (int64_t)b * a.w.cin * a.lin;
+  const int cgs = a.w.cin_pad16 >> 4;
+  // plane 0 of (phase, tap 0, group 0), rows from co0
+  const bf16_t* wph = a.w.wb + ((((int64_t)phase * taps * cgs * 3) * a.w.cout_pad + co0) << 4);
+  const bool do_snake = a.snake_alpha != nullptr;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int qw = wave * NT * 32;
+  const int n_rows = taps * G * NP;    // (tap, group, plane) rows of the weight tile, MT KiB each
+  const int nblk = (wx + 63) >> 6;
+  const char* a_lane = Ws + li * 32 + (((lk ^ (li >> 3)) & 1) << 4);
+
+  // (A register prefetch of the next step's input tile before the matrix phase was measured and is NOT used: 111.9 vs
+  // 106.2 ms per batch-8 decode -- the waves wait on the barrier-separated phases, not on that load latency.)
+  for (int cg0 = 0; cg0 < cgs; cg0 += G) {
+    for (int p = wave; p < n_rows * MT; p += 4) {
+      const int row = p / MT, pc = p - row * MT;
+      const int pl = row % NP, tg = row / NP;
+      const int tp = tg / G, g = tg - tp * G;
+      const char* gsrc = reinterpret_cast<const char*>(wph + (((((int64_t)tp * cgs + cg0 + g) * 3 + pl) * a.w.cout_pad) << 4)) +
+                         pc * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)(Ws + p * 1024), 16, 0, 0);
+    }
+    // input tile: item = (group, 8-channel half, 64-column block); a lane owns one column, splits its 8 channels
+    for (int it = wave; it < 2 * G * nblk; it += 4) {
+      const int pair = it / nblk, cb = it - pair * nblk;
+      const int g = pair >> 1, h = pair & 1;
+      const int c = cb * 64 + lane;
+      const int ci = (cg0 + g) * 16 + h * 8;   // wave-uniform
+      const int col = c0 + c;
+      const int nval = a.w.cin - ci;           // real channels among the 8 (padding reads as zero)
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (c < wx) {
+        if (col >= 0 && col < a.lin && nval > 0) {
+          const float* xp = xb + (int64_t)ci * a.lin + col;
+          if (nval >= 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xp[(int64_t)e * a.lin];
+            if (do_snake) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = snake_f(v[e], a.snake_alpha[ci + e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e < nval) {
+                const float t = xp[(int64_t)e * a.lin];
+                v[e] = do_snake ? snake_f(t, a.snake_alpha[ci + e]) : t;
+              }
+          }
+        }
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t hh, mm, ll;
+          split3_pk(v[2 * e], v[2 * e + 1], hh, mm, ll);
+          ph[e] = hh; pm[e] = mm; pl[e] = ll;
+        }
+        char* dst = Xs + ((int64_t)(g * NP) * wx + c) * 32 + (((h ^ (c >> 3)) & 1) << 4);
+        *reinterpret_cast<u32x4*>(dst) = ph;
+        if (NP > 1) *reinterpret_cast<u32x4*>(dst + (int64_t)wx * 32) = pm;
+        if (NP > 2) *reinterpret_cast<u32x4*>(dst + (int64_t)2 * wx * 32) = pl;
+      }
+    }
+    __syncthreads();   // drains the LDS-DMA too (vmcnt(0) is part of the barrier's fence)
+#pragma unroll(TAPS > 0 ? TAPS : 1)
+    for (int tp = 0; tp < taps; ++tp) {
+      const int xoff = tap_off0 + tp * a.tap_step;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        bf16x8 af[NP][MT], bf[NP][NT];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            af[pl][i] = *reinterpret_cast<const bf16x8*>(a_lane + (((tp * G + g) * NP + pl) * CO_T + i * 32) * 32);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int c = (qw + j * 32 + li) * a.x_stride + xoff;
+            bf[pl][j] = *reinterpret_cast<const bf16x8*>(Xs + ((int64_t)(g * NP + pl) * wx + c) * 32 + (((lk ^ (c >> 3)) & 1) << 4));
+          }
+        }
+        // partial products, smallest first
+#define FMI_PROD(PA, PB)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)         \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][i], bf[PB][j], acc[i][j], 0, 0, 0)
+        if constexpr (NP > 2) {
+          FMI_PROD(2, 0);
+          FMI_PROD(0, 2);
+          FMI_PROD(1, 1);
+        }
+        if constexpr (NP > 1) {
+          FMI_PROD(1, 0);
+          FMI_PROD(0, 1);
+        }
+        FMI_PROD(0, 0);
+#undef FMI_PROD
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (as conv_mfma_kernel): out = res + gamma * act(acc + bias)
+  float* sb = smem;
+  float* sg = smem + CO_T;
+  const int co_last = a.w.cout - 1;
+  if (tid < CO_T) {
+    const int co = min(co0 + tid, co_last);
+    sb[tid] = a.w.bias ? a.w.bias[co] : 0.f;
+    sg[tid] = a.gamma ? a.gamma[co] : 1.f;
+  }
+  __syncthreads();
+  float* ob = a.out + (int64_t)b * a.w.cout * a.lout;
+  const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : ob;
+  const bool has_res = a.res != nullptr;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int q = q0 + qw + j * 32 + li;
+      const bool live = q < ncols;
+      const int col = (live ? q : 0) * a.out_stride + phase;
+      const int row0 = i * 32 + 4 * lk;
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = min(co0 + row0 + 8 * (r >> 2) + (r & 3), co_last);
+        rv[r] = has_res ? rb[co * a.lout + col] : 0.f;
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb + row0 + 8 * r4);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg + row0 + 8 * r4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = r4 * 4 + e;
+          float v = acc[i][j][r] + b4[e];
+          if (a.act == ACT_GELU) v = gelu_f(v);
+          v = v * g4[e] + rv[r];
+          const int co = co0 + row0 + 8 * r4 + e;
+          if (live && co <= co_last) ob[co * a.lout + col] = v;
+        }
+      }
+    }
+}
+
+template <int MT, int NT, int G, int NP, int TAPS>
+static int launch_conv_bf16_tt(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
+  const ConvW& w = a.w;
+  constexpr int TT = 4 * NT * 32, CO_T = MT * 32;
+  const int wx = (TT - 1) * a.x_stride + span;
+  const size_t smem = (size_t)(G * NP * wx + w.taps * G * NP * CO_T) * 32;
+  FMI_REQUIRE(smem <= 160 * 1024, "conv(bf16): LDS tile of %zu bytes exceeds 160 KiB", smem);
+  FMI_REQUIRE(w.cout_pad % CO_T == 0 && (w.cin_pad16 >> 4) % G == 0, "conv(bf16): tile does not divide the packed weight");
+  dim3 grid(cdiv(ncols, TT), w.cout_pad / CO_T, a.B * w.phases), block(256);
+  if (smem > 64 * 1024)
+    FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_bf16_kernel<MT, NT, G, NP, TAPS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<MT, NT, G, NP, TAPS>), grid, block, smem, s, a, ncols, wx, tap_off0);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+template <int MT, int NT, int G, int NP>
+static int launch_conv_bf16_t(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
+  static const bool unroll7 = []() { const char* e = getenv("FMI_CONV_UNROLL7"); return !e || atoi(e) != 0; }();
+  if (G == 1 && a.w.taps == 7 && unroll7) return launch_conv_bf16_tt<MT, NT, G, NP, 7>(a, ncols, tap_off0, span, s);
+  return launch_conv_bf16_tt<MT, NT, G, NP, 0>(a, ncols, tap_off0, span, s);
+}
+
+template <int NP>
+static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
+  const ConvW& w = a.w;
+  const int ct = w.cout_pad / 32;
+  static const int env_mt = []() { const char* e = getenv("FMI_CONV_MT"); return e ? atoi(e) : 0; }();
+  int MT = 1;
+  for (int m : {4, 3, 2})
+    if (ct % m == 0) { MT = m; break; }
+  // the weight tile is NP planes of taps x 16 channels: 128 rows x 7 taps x 3 planes is 84 KiB -- one work-group per
+  // CU; 64 rows keep two resident, which hides the staging phase of one behind the matrix phase of the other
+  const size_t wbytes = (size_t)w.taps * NP * MT * 32 * 32;
+  if (MT == 4 && wbytes > 48 * 1024) MT = 2;
+  if (env_mt >= 1 && env_mt <= 4 && ct % env_mt == 0) MT = env_mt;
+  const bool k1 = (w.taps == 1 && a.x_stride == 1 && (w.cin_pad16 >> 4) % 2 == 0);
+#define FMI_CONVB(MT_, NT_)                                                              \
+  return k1 ? launch_conv_bf16_t<MT_, NT_, 2, NP>(a, ncols, tap_off0, span, s)           \
+            : launch_conv_bf16_t<MT_, NT_, 1, NP>(a, ncols, tap_off0, span, s)
+  if (MT == 4) FMI_CONVB(4, 1);
+  if (MT == 3) FMI_CONVB(3, 2);
+  if (MT == 2) FMI_CONVB(2, 2);
+  FMI_CONVB(1, 4);
+#undef FMI_CONVB
+}
+
 template <int MT, int NT, int G>
 static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
   const ConvW& w = a.w;
@@ -292,6 +573,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   const int ncols = (a.out_stride == 1) ? a.lout : a.lout / a.out_stride;
   const int tap_off0 = (a.tap_step < 0) ? -(w.taps - 1) * a.tap_step : 0;
   const int span = (w.taps - 1) * (a.tap_step < 0 ? -a.tap_step : a.tap_step) + 1;
+  if (a.planes > 0) {
+    FMI_REQUIRE(w.wb && w.cin_pad16 % 16 == 0, "conv: this layer has no bf16 planes (planes=%d requested)", a.planes);
+    if (a.planes == 1) return launch_conv_bf16<1>(a, ncols, tap_off0, span, s);
+    if (a.planes == 2) return launch_conv_bf16<2>(a, ncols, tap_off0, span, s);
+    return launch_conv_bf16<3>(a, ncols, tap_off0, span, s);
+  }
   const int ct = w.cout_pad / 32;
   // tile height: the largest of 4/3/2/1 (x32 rows) that divides the channel tiles, so that no
   // work-group multiplies padding (C = 192 -> 2 x 96, not 128 + 64) and every DMA piece is inside the weight

@@ -246,6 +246,12 @@ class MiDAC:
     def weights_ready(self):
         check(self.lib.fmi_dac_weights_ready(self._h))
 
+    def set_precision(self, planes: int):
+        """Decode-side contraction arithmetic: 3 = bf16 matrix cores on three-way operand splits (fp32-class, the
+        default), 0 = fp32 matrix cores (round-1 path), 2 / 1 = fewer bf16 planes (see include/fishmi.h)."""
+        check(self.lib.fmi_dac_set_precision(self._h, int(planes)))
+        return self
+
     @classmethod
     def from_state_dict(cls, config, state, device="cuda:0") -> "MiDAC":
         return cls(config, device=device).load_state_dict(state)

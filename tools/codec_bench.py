@@ -15,7 +15,17 @@ codes = torch.randint(0, 1024, (B, 10, T), generator=g, device=dev, dtype=torch.
 codec.from_indices(codes.clone()); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 flop = 2 * 727.15e9 * B * T / 215
-for dbg in os.environ.get("DBG_MODES", "0").split(","):
+for planes in [int(v) for v in os.environ.get("PLANES", "3,0,2,1").split(",")]:
+    codec.set_precision(planes)
+    codec.from_indices(codes.clone()); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        e0.record(); out = codec.from_indices(codes.clone()); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
+    print(f"planes={planes} FMI_CONV_MT={os.environ.get('FMI_CONV_MT', '-')} decode B={B} T={T}: {min(ts):.1f} ms  ({flop / min(ts) / 1e9:.1f} TFLOP/s useful)  checksum {float(out.double().abs().sum()):.6f}", flush=True)
+codec.set_precision(0)
+for dbg in os.environ.get("DBG_MODES", "").split(","):
+    if not dbg:
+        continue
     os.environ["FMI_CONV_DBG"] = dbg
     ts = []
     for _ in range(3):
