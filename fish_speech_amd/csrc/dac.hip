@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -116,6 +117,9 @@ struct fmi_dac {
   // default), 0 = fp32 matrix cores, 2 / 1 = fewer planes.  The encoder always runs on the fp32 matrix cores.
   int decode_planes = 3;
   int cur_planes = 0;
+  // one workspace per handle: request threads that share the codec object (inference_engine/__init__.py:179-192,
+  // tools/api_server.py:115-122) are serialised here, whole call by whole call
+  std::mutex mu;
   std::vector<ConvW> plane_jobs;
 };
 
@@ -553,6 +557,8 @@ int fmi_dac_frame_length(const fmi_dac* h) { return h ? frame_length(h->cfg) : 0
 
 int fmi_dac_load_tensor(fmi_dac* h, const char* name_c, const float* src, int ndim, const int64_t* dims,
                         int src_is_device, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h && name_c && src && dims && ndim >= 1 && ndim <= 3, "bad argument");
   const std::string name(name_c);
   if (name == "rope_table") {  // bf16 (positions, head_dim) table built by the host with torch
@@ -609,6 +615,8 @@ int fmi_dac_load_tensor(fmi_dac* h, const char* name_c, const float* src, int nd
 }
 
 int fmi_dac_finalize_weights(fmi_dac* h, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h, "null handle");
   for (auto& kv : h->reg)
     if (!kv.second.loaded) return set_error(FMI_ESTATE, "codec tensor '%s' was never loaded", kv.first.c_str());
@@ -648,6 +656,8 @@ int fmi_dac_finalize_weights(fmi_dac* h, void* stream) {
 }
 
 int fmi_dac_set_precision(fmi_dac* h, int planes) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h, "null handle");
   FMI_REQUIRE(planes >= 0 && planes <= 3, "planes must be 0 (fp32 matrix cores) or 1..3 (bf16 planes)");
   h->decode_planes = planes;
@@ -661,6 +671,8 @@ int fmi_dac_weights_ready(fmi_dac* h) {
 }
 
 int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_out_dev, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h && indices_dev && audio_out_dev, "null argument");
   FMI_REQUIRE(h->ready, "codec weights not ready");
   FMI_REQUIRE(B >= 1 && T >= 1, "empty input");
@@ -676,6 +688,8 @@ int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_
 int fmi_dac_context_frames(const fmi_dac* h) { return h ? cdiv(decoder_context_cols(h->cfg), 4) : 0; }
 
 int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, float* audio_out_dev, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h && indices_dev && audio_out_dev, "null argument");
   FMI_REQUIRE(h->ready, "codec weights not ready");
   FMI_REQUIRE(B >= 1 && T >= 1 && t0 >= 0 && t0 < T, "bad frame range [%d, %d)", t0, T);
@@ -699,6 +713,8 @@ int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, 
 }
 
 int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* audio_out_dev, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h && z_dev && audio_out_dev, "null argument");
   FMI_REQUIRE(h->ready, "codec weights not ready");
   FMI_REQUIRE(B >= 1 && L >= 1, "empty input");
@@ -723,6 +739,8 @@ int fmi_dac_debug_z(fmi_dac* h, float** z_dev, int* C, int* L) {
 }
 
 int fmi_dac_encode(fmi_dac* h, const float* audio_dev, int B, int N, int64_t* indices_out_dev, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h && audio_dev && indices_out_dev, "null argument");
   FMI_REQUIRE(h->ready, "codec weights not ready");
   const fmi_dac_config& c = h->cfg;

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
   const int co_last = a.w.cout - 1;
   if (tid < CO_T) {
     const int co = min(co0 + tid, co_last);
-    sb[tid] = a.w.bias ? a.w.bias[co] : 0.f;
+    sb[tid] = a.w.bias ? (NP == 1 ? rbf(a.w.bias[co]) : a.w.bias[co]) : 0.f;
     sg[tid] = a.gamma ? a.gamma[co] : 1.f;
   }
   __syncthreads();
@@ -493,8 +493,12 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
         for (int e = 0; e < 4; ++e) {
           const int r = r4 * 4 + e;
           float v = acc[i][j][r] + b4[e];
-          if (a.act == ACT_GELU) v = gelu_f(v);
-          v = v * g4[e] + rv[r];
+          if (NP == 1) v = rbf(v);   // autocast(bf16): the conv / linear returns bf16 (bias already bf16-rounded)
+          if (a.act == ACT_GELU) {
+            v = gelu_f(v);
+            if (NP == 1) v = rbf(v);  // GELU of a bf16 tensor is a bf16 tensor
+          }
+          v = v * g4[e] + rv[r];     // LayerScale / ConvNeXt gamma (fp32 parameter) and the residual promote to fp32
           const int co = co0 + row0 + 8 * r4 + e;
           if (live && co <= co_last) ob[co * a.lout + col] = v;
         }

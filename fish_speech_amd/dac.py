@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from dataclasses import dataclass
 from typing import Dict, Iterable, Optional, Tuple
 
@@ -198,6 +199,8 @@ class MiDAC:
         self.frame_length = self.config.frame_length
         self.hop_length = int(math.prod(self.config.encoder_rates))
         self._dtype_probe = torch.empty(0, dtype=torch.float32, device=self.device)
+        self._planes = 3                       # decode-side arithmetic outside autocast (set_precision)
+        self._lock = threading.RLock()         # (precision, call) pairs of concurrent request threads stay together
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -249,8 +252,31 @@ class MiDAC:
     def set_precision(self, planes: int):
         """Decode-side contraction arithmetic: 3 = bf16 matrix cores on three-way operand splits (fp32-class, the
         default), 0 = fp32 matrix cores (round-1 path), 2 / 1 = fewer bf16 planes (see include/fishmi.h)."""
-        check(self.lib.fmi_dac_set_precision(self._h, int(planes)))
+        with self._lock:
+            check(self.lib.fmi_dac_set_precision(self._h, int(planes)))
+            self._planes = int(planes)
         return self
+
+    def _decode_call(self, fn, *args):
+        """Run one decode-side entry point with the arithmetic the caller's context asks for: inside
+        ``torch.autocast(device_type="cuda", dtype=torch.bfloat16)`` -- how the engine calls from_indices
+        (fish_speech/inference_engine/__init__.py:179-192) -- every conv / linear rounds its operands and its result to
+        bf16 with fp32 accumulation, as autocast does to F.conv1d / F.conv_transpose1d / F.linear; elementwise ops,
+        norms and residual adds stay fp32 (torch's type promotion gives fp32 there too, parameters being fp32).
+        Outside autocast the configured precision applies (default: fp32-class three-plane arithmetic)."""
+        planes = self._planes
+        if torch.is_autocast_enabled():
+            if torch.get_autocast_gpu_dtype() != torch.bfloat16:
+                raise _lib.FishmiError("MiDAC supports autocast(dtype=torch.bfloat16) only (the engine's --half fp16 mode "
+                                       "is not implemented)")
+            planes = 1
+        with self._lock:
+            check(self.lib.fmi_dac_set_precision(self._h, planes))
+            try:
+                check(fn(self._h, *args))
+            finally:
+                if planes != self._planes:
+                    check(self.lib.fmi_dac_set_precision(self._h, self._planes))
 
     @classmethod
     def from_state_dict(cls, config, state, device="cuda:0") -> "MiDAC":
@@ -286,7 +312,7 @@ class MiDAC:
         if nb != self.config.n_codebooks + 1:
             raise ValueError(f"expected {self.config.n_codebooks + 1} codebooks, got {nb}")
         out = torch.empty(B, 1, T * self.frame_length, dtype=torch.float32, device=self.device)
-        check(self.lib.fmi_dac_decode(self._h, C.c_void_p(work.data_ptr()), B, T, C.c_void_p(out.data_ptr()), self._stream()))
+        self._decode_call(self.lib.fmi_dac_decode, C.c_void_p(work.data_ptr()), B, T, C.c_void_p(out.data_ptr()), self._stream())
         if work is not indices:
             try:
                 indices.copy_(work)  # the reference mutates its argument; keep that visible to the caller
@@ -307,8 +333,8 @@ class MiDAC:
         if not 0 <= t0 < T:
             raise ValueError(f"t0={t0} outside [0, {T})")
         out = torch.empty(B, 1, (T - t0) * self.frame_length, dtype=torch.float32, device=self.device)
-        check(self.lib.fmi_dac_decode_tail(self._h, C.c_void_p(work.data_ptr()), B, T, int(t0),
-                                           C.c_void_p(out.data_ptr()), self._stream()))
+        self._decode_call(self.lib.fmi_dac_decode_tail, C.c_void_p(work.data_ptr()), B, T, int(t0),
+                          C.c_void_p(out.data_ptr()), self._stream())
         self._keep = work
         return out
 
@@ -325,7 +351,7 @@ class MiDAC:
         if Cc != self.config.latent_dim:
             raise ValueError(f"expected {self.config.latent_dim} latent channels, got {Cc}")
         out = torch.empty(B, 1, L * self.hop_length, dtype=torch.float32, device=self.device)
-        check(self.lib.fmi_dac_decode_latent(self._h, C.c_void_p(z.data_ptr()), B, L, C.c_void_p(out.data_ptr()), self._stream()))
+        self._decode_call(self.lib.fmi_dac_decode_latent, C.c_void_p(z.data_ptr()), B, L, C.c_void_p(out.data_ptr()), self._stream())
         self._keep = z
         return out
 

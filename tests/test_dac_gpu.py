@@ -244,3 +244,68 @@ def test_bf16_plane_arithmetic_vs_fp32_matrix_cores_and_oracle(full):
     assert e[3][1] <= 1e-6
     assert e[2][1] <= 1e-4
     assert e[1][1] <= 5e-2 * max(sig, 1e-3) + 1e-3
+
+
+def test_engine_autocast_bf16_mode_vs_oracle_in_the_same_mode(full):
+    """How the engine calls the codec (fish_speech/inference_engine/__init__.py:179-192): from_indices under
+    torch.autocast(bfloat16) over fp32 weights.  Inside autocast MiDAC rounds the operands and the result of every
+    conv / linear to bf16 (fp32 accumulation), like autocast does to F.conv1d / F.conv_transpose1d / F.linear.
+    Tolerance, calibrated instead of guessed: the oracle is run on the CPU under the same autocast context and in
+    fp32; the HIP result must be as close to the exact fp32 waveform as the reference arithmetic in that mode is
+    (<= 1.5x its RMS distance) and within 2x that distance of the autocast oracle itself -- two bf16 evaluations of
+    the same network differ by their rounding noise, not more."""
+    cfg, state, codec = full
+    codes = D.make_codes(cfg, 2, 4, seed=12)
+    orc = D.DacOracle(cfg, state)
+    want32 = orc.from_indices(codes.clone())
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        want_ac = orc.from_indices(codes.clone()).float()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        got = codec.from_indices(codes.clone().to(DEV)).float().cpu()
+    plain = codec.from_indices(codes.clone().to(DEV)).cpu()       # outside autocast: fp32-class again
+    sig = float(want32.pow(2).mean().sqrt())
+    noise, e_hip, e_x = rms(want_ac, want32), rms(got, want32), rms(got, want_ac)
+    print(f"autocast(bf16): signal rms {sig:.4f}; vs exact fp32: oracle {noise:.2e}, HIP {e_hip:.2e}; HIP vs autocast oracle {e_x:.2e}")
+    assert noise > 1e-5, "the autocast oracle should differ visibly from fp32"
+    assert e_hip <= 1.5 * noise + 1e-5 and e_x <= 2.0 * noise + 1e-5
+    assert rms(plain, want32) <= 1e-4
+    with pytest.raises(Exception):
+        with torch.autocast("cuda", dtype=torch.float16):
+            codec.from_indices(codes.clone().to(DEV))
+
+
+def test_concurrent_from_indices_from_request_threads(small):
+    """request threads share the codec object (tools/api_server.py:115-122 -> get_audio_segment).  Four
+    threads decode different codes at once, some inside autocast: every result equals the sequential one."""
+    import threading
+
+    cfg, state, z, codec = small
+    jobs = [(D.make_codes(cfg, 1 + i % 2, 3 + i, seed=50 + i), i % 2 == 1) for i in range(4)]
+
+    def run(codes, ac):
+        if ac:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return codec.from_indices(codes.clone().to(DEV)).float().cpu()
+        return codec.from_indices(codes.clone().to(DEV)).cpu()
+
+    want = [run(c, ac) for c, ac in jobs]
+    got = [[None] * 6 for _ in jobs]
+    errs = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            for r in range(6):
+                got[i][r] = run(*jobs[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        for r in range(6):
+            assert torch.equal(got[i][r], want[i]), (i, r)
