@@ -57,6 +57,8 @@ _SIGS = {
     "fmi_dualar_setup_caches": (C.c_int, [_P, _I, _I]),
     "fmi_dualar_prefill": (C.c_int, [_P, _I, C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.POINTER(SamplingC), _P]),
+    "fmi_dualar_prefill_resume": (C.c_int, [_P, _I, C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.POINTER(SamplingC), _P]),
     "fmi_dualar_decode": (C.c_int, [_P, _I, C.POINTER(C.c_int32), _I, _P]),
     "fmi_dualar_read": (C.c_int, [_P, _I, C.POINTER(C.c_int32), _I, C.POINTER(_I), C.POINTER(_I), _P]),
     "fmi_dualar_poll_done": (C.c_int, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),

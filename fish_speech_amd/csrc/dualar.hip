@@ -75,6 +75,7 @@ struct fmi_dualar {
   bf16_t *qkv0_tab = nullptr, *qkv0_pre = nullptr;
   bool qkv0_tried = false;
   bool trace = false, use_graph = true, ignore_eos = false;
+  bool force_tiled = false;
   int attn_impl = 1;   // prefill attention: 1 = MFMA flash kernel with LDS-staged K/V tiles, 0 = VALU kernel (A/B parity)
   int max_top_k = 0;  // largest top_k over the LIVE slots (selects the sampler variant the graphs embed)
   std::vector<int> slot_top_k;  // per slot, 0 = released
@@ -251,7 +252,9 @@ int linear(fmi_dualar* h, const bf16_t* x, int ldx, const bf16_t* wp, const bf16
   LinearArgs a{};
   a.wp = wp; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = h->cfg.norm_eps; a.res = res; a.ldr = ldr;
   a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epi = epi; a.wq = wq; a.scale = scale;
-  if (M <= 16) {
+  // h->force_tiled: the few suffix rows of a resumed prefill must go through the kernel a full prefill of the
+  // whole prompt would have used for them (the tiled GEMM: a row's bits do not depend on how many rows run along)
+  if (M <= 16 && !h->force_tiled) {
     h->launches += 1;
     return launch_linear_skinny(a, s);
   }
@@ -797,35 +800,49 @@ int fmi_dualar_release(fmi_dualar* h, int slot) {
 
 static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int32_t* tokens_dev, const int32_t* lens,
                         const int32_t* max_new, const fmi_sampling* samp, int frame_index, hipStream_t s,
-                        bool head_only = false) {
+                        bool head_only = false, const int32_t* pos0 = nullptr) {
   const fmi_dualar_config& c = h->cfg;
   FMI_CHECK(ensure_qkv0_table(h));
   int rows = 0;
+  bool any_long = false;
   for (int i = 0; i < n; ++i) {
     FMI_CHECK(check_slot(h, slot_ids[i]));
     FMI_REQUIRE(lens[i] >= 1, "empty prompt for slot %d", slot_ids[i]);
-    if (lens[i] >= h->max_seq)  // inference.py:263-266
-      return set_error(FMI_EINVAL, "Input sequence length %d exceeds max_seq_len %d", lens[i], h->max_seq);
+    const int p0 = pos0 ? pos0[i] : 0;
+    FMI_REQUIRE(p0 >= 0, "negative resume position");
+    if (p0 > 0)
+      FMI_REQUIRE((int)h->slot_pages[slot_ids[i]].size() * KV_PAGE >= p0,
+                  "slot %d holds no K/V for positions below %d (released?)", slot_ids[i], p0);
+    if (p0 + lens[i] >= h->max_seq)  // inference.py:263-266
+      return set_error(FMI_EINVAL, "Input sequence length %d exceeds max_seq_len %d", p0 + lens[i], h->max_seq);
     rows += lens[i];
+    any_long = any_long || p0 + lens[i] > 16;
   }
+  struct TiledGuard {   // resumed prefill: suffix rows use the full prefill's kernels (see linear())
+    fmi_dualar* h;
+    ~TiledGuard() { h->force_tiled = false; }
+  } guard{h};
+  h->force_tiled = pos0 != nullptr && any_long;
   FMI_CHECK(ensure_rows(h, std::max(rows, h->max_batch)));
   std::vector<int32_t> row_slot(rows), row_pos(rows), last(n), slots(n);
   std::vector<int4> tiles;
   int r = 0;
   for (int i = 0; i < n; ++i) {
+    const int p0 = pos0 ? pos0[i] : 0;
+    const int full = p0 + lens[i];          // prompt length as generate() sees it
     int mn = max_new[i];
-    if (mn <= 0 || lens[i] + mn > h->max_seq) mn = h->max_seq - lens[i];  // inference.py:268-275
-    const int limit = lens[i] + mn - 1;
+    if (mn <= 0 || full + mn > h->max_seq) mn = h->max_seq - full;  // inference.py:268-275
+    const int limit = full + mn - 1;
     // positions 0..limit-1 receive K/V; a slot that ends AT its limit parks its position counter on `limit`, so
     // the block-table entry of that position must be the slot's own page too (the decode attention additionally
     // stops appending once SlotState.done is set)
-    FMI_CHECK(reserve_pages(h, slot_ids[i], std::min(std::max(limit, lens[i]) + 1, h->max_seq)));
-    FMI_CHECK(set_slot(h, slot_ids[i], lens[i], frame_index, limit, samp[i], frame_index == 0));
+    FMI_CHECK(reserve_pages(h, slot_ids[i], std::min(std::max(limit, full) + 1, h->max_seq)));
+    FMI_CHECK(set_slot(h, slot_ids[i], full, frame_index, limit, samp[i], frame_index == 0));
     for (int t0 = 0; t0 < lens[i]; t0 += 16)
-      tiles.push_back(make_int4(r + t0, std::min(16, lens[i] - t0), slot_ids[i], t0));
+      tiles.push_back(make_int4(r + t0, std::min(16, lens[i] - t0), slot_ids[i], p0 + t0));
     for (int t = 0; t < lens[i]; ++t, ++r) {
       row_slot[r] = slot_ids[i];
-      row_pos[r] = t;
+      row_pos[r] = p0 + t;
     }
     last[i] = r - 1;
     slots[i] = slot_ids[i];
@@ -851,6 +868,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
   // the tail addresses slots through row_slot[0..n)
   FMI_CHECK_HIP(hipMemcpyAsync(ws.row_slot, slots.data(), n * 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipStreamSynchronize(s));
+  h->force_tiled = false;   // the head and the fast chain see n <= 16 rows in a full prefill too
   if (head_only) return tail_head(h, h->xl, n, s);
   return tail(h, h->xl, n, ws.row_slot, s);
 }
@@ -862,6 +880,17 @@ int fmi_dualar_prefill(fmi_dualar* h, int n, const int32_t* slot_ids, const int3
   FMI_REQUIRE(n >= 1 && n <= h->max_batch, "n=%d out of range", n);
   FMI_CHECK(sync_in(h, stream));
   FMI_CHECK(prefill_impl(h, n, slot_ids, tokens_dev, lens, max_new, samp, 0, h->stream));
+  return sync_out(h, stream);
+}
+
+int fmi_dualar_prefill_resume(fmi_dualar* h, int n, const int32_t* slot_ids, const int32_t* tokens_dev,
+                              const int32_t* lens, const int32_t* pos0, const int32_t* max_new,
+                              const fmi_sampling* samp, void* stream) {
+  FMI_REQUIRE(h && slot_ids && tokens_dev && lens && pos0 && max_new && samp, "null argument");
+  FMI_REQUIRE(h->ready, "weights not ready");
+  FMI_REQUIRE(n >= 1 && n <= h->max_batch, "n=%d out of range", n);
+  FMI_CHECK(sync_in(h, stream));
+  FMI_CHECK(prefill_impl(h, n, slot_ids, tokens_dev, lens, max_new, samp, 0, h->stream, false, pos0));
   return sync_out(h, stream);
 }
 

@@ -220,6 +220,9 @@ class MiDualAR:
         self.max_seq_len = -1
         self._frame_index = 0
         self._ignore_eos = False
+        self._cached_prompt: Dict[int, torch.Tensor] = {}   # slot -> prompt columns whose prefill K/V it still holds
+        self.prefilled_rows = 0                             # bookkeeping for tests / reports
+        self.reused_rows = 0
         self._seed_counter = itertools.count()
         self._dtype_probe = torch.empty(0, dtype=torch.bfloat16, device=self.device)
         self.fixed_temperature = torch.tensor(0.7, device=self.device)
@@ -415,17 +418,49 @@ class MiDualAR:
         if codes.numel() and (int(codes.min()) < 0 or int(codes.max()) >= cfg.codebook_size):
             raise IndexError(f"codebook index out of range [0, {cfg.codebook_size})")
 
+    def _reusable_prefix(self, slot: int, prompt: torch.Tensor) -> int:
+        """Number of leading columns of `prompt` whose K/V the slot still holds from an earlier PREFILL of the same
+        columns (0 if none).  At least one column is always left to run: it produces the frame's logits."""
+        old = self._cached_prompt.get(slot)
+        if old is None:
+            return 0
+        new = prompt.detach().to("cpu", torch.int64)
+        m = min(old.shape[1], new.shape[1] - 1)
+        if m <= 0:
+            return 0
+        same = (old[:, :m] == new[:, :m]).all(dim=0)
+        bad = (~same).nonzero()
+        return int(bad[0]) if len(bad) else m
+
     def prefill(self, slots: Sequence[int], prompts: Sequence[torch.Tensor], max_new_tokens: Sequence[int],
-                sampling: Sequence[SamplingC]):
-        """prompts[i]: (1+ncb, T_i) integer tensor (the reference's prompt layout)."""
+                sampling: Sequence[SamplingC], reuse_prefix: bool = False):
+        """prompts[i]: (1+ncb, T_i) integer tensor (the reference's prompt layout).  With `reuse_prefix` the slot's
+        pages are kept between calls (do not release it) and only the columns after the longest prefix the cache
+        already holds are run (fmi_dualar_prefill_resume): bit-identical to running the whole prompt."""
         n = len(slots)
-        toks = torch.cat([p.to(self.device).t().to(torch.int32) for p in prompts], dim=0).contiguous()
+        pos0 = [0] * n
+        if reuse_prefix:   # prefix-KV reuse (generate_long's chunks): skip what the slot's cache already holds
+            pos0 = [self._reusable_prefix(int(s), p) for s, p in zip(slots, prompts)]
+        for s, p0 in zip(slots, pos0):
+            if p0 == 0 and self._cached_prompt.pop(int(s), None) is not None:
+                self.release(int(s))          # the retained pages belong to another conversation
+        toks = torch.cat([p[:, p0:].to(self.device).t().to(torch.int32) for p, p0 in zip(prompts, pos0)], dim=0).contiguous()
         self._check_tokens(toks)
-        lens = (C.c_int32 * n)(*[int(p.shape[1]) for p in prompts])
+        lens = (C.c_int32 * n)(*[int(p.shape[1]) - p0 for p, p0 in zip(prompts, pos0)])
         sl = (C.c_int32 * n)(*[int(s) for s in slots])
         mn = (C.c_int32 * n)(*[int(m) for m in max_new_tokens])
         sp = (SamplingC * n)(*sampling)
-        check(self.lib.fmi_dualar_prefill(self._h, n, sl, C.c_void_p(toks.data_ptr()), lens, mn, sp, self._stream()))
+        if any(pos0):
+            p0c = (C.c_int32 * n)(*pos0)
+            check(self.lib.fmi_dualar_prefill_resume(self._h, n, sl, C.c_void_p(toks.data_ptr()), lens, p0c, mn, sp,
+                                                     self._stream()))
+        else:
+            check(self.lib.fmi_dualar_prefill(self._h, n, sl, C.c_void_p(toks.data_ptr()), lens, mn, sp, self._stream()))
+        self.prefilled_rows += sum(int(p.shape[1]) - p0 for p, p0 in zip(prompts, pos0))
+        self.reused_rows += sum(pos0)
+        if reuse_prefix:   # positions [0, T) now hold prefill-written K/V of exactly these columns
+            for s, p in zip(slots, prompts):
+                self._cached_prompt[int(s)] = p.detach().to("cpu", torch.int64).clone()
         self._keep = toks
 
     def decode(self, slots: Sequence[int], n_frames: int):
@@ -460,6 +495,7 @@ class MiDualAR:
         return full[:n_slots, :n_frames]
 
     def release(self, slot: int):
+        self._cached_prompt.pop(int(slot), None)
         check(self.lib.fmi_dualar_release(self._h, int(slot)))
 
     def last_decode_stats(self):
@@ -583,18 +619,21 @@ def decode_one_token(model: MiDualAR, x: torch.Tensor, input_pos: torch.Tensor, 
 @torch.no_grad()
 def generate(*, model: MiDualAR, prompt: torch.Tensor, max_new_tokens: int, audio_masks=None, audio_parts=None,
              decode_one_token=None, num_samples: int = 1, poll_every: int = 16, seed: Optional[int] = None,
-             stop_on_im_end: bool = True, **sampling_kwargs) -> torch.Tensor:
+             stop_on_im_end: bool = True, reuse_prefix: bool = False, **sampling_kwargs) -> torch.Tensor:
     """Drop-in for generate (inference.py:243-359) on one utterance, without the per-frame host sync:
-    frames advance by hipGraph replay and <|im_end|> is polled every ``poll_every`` frames."""
+    frames advance by hipGraph replay and <|im_end|> is polled every ``poll_every`` frames.  ``reuse_prefix``: keep
+    the slot's K/V afterwards and, next time, run only the prompt columns beyond the longest prefix it shares with
+    this prompt (generate_long's chunks repeat the whole conversation so far) -- results are bit-identical."""
     return generate_batch(model=model, prompts=[prompt], max_new_tokens=max_new_tokens, poll_every=poll_every,
                           seeds=None if seed is None else [seed], stop_on_im_end=stop_on_im_end,
-                          **sampling_kwargs)[0]
+                          reuse_prefix=reuse_prefix, **sampling_kwargs)[0]
 
 
 @torch.no_grad()
 def generate_batch(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_tokens: int, poll_every: int = 16,
                    seeds: Optional[Sequence[int]] = None, stop_on_im_end: bool = True, temperature: float = 1.0,
-                   top_p: float = 0.9, top_k: int = 30, use_ras: bool = True) -> List[torch.Tensor]:
+                   top_p: float = 0.9, top_k: int = 30, use_ras: bool = True, reuse_prefix: bool = False
+                   ) -> List[torch.Tensor]:
     """Batch of utterances through prefill + graph-replayed decode.  Each result equals what the
     batch-1 path yields for that utterance (kernels are batch-invariant).  Returns, per utterance,
     (1+ncb, T_i + n_i) like the reference's ``generate``."""
@@ -615,7 +654,7 @@ def generate_batch(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_
     slots = list(range(n))
     seeds = list(seeds) if seeds is not None else [model.next_seed() for _ in range(n)]
     samp = [model._sampling(temperature, top_p, top_k, seeds[i], use_ras) for i in range(n)]
-    model.prefill(slots, prompts, mn, samp)
+    model.prefill(slots, prompts, mn, samp, reuse_prefix=reuse_prefix)
     remaining = max(mn) - 1
     while remaining > 0:
         step = min(poll_every, remaining)
@@ -628,7 +667,8 @@ def generate_batch(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_
         frames, done = model.read(i)
         seq = torch.cat([p.to("cpu", torch.int64), frames.t().to(torch.int64)], dim=1)
         outs.append(seq.to(p.dtype) if p.dtype in (torch.int32, torch.int64) else seq)
-        model.release(i)
+        if not reuse_prefix:
+            model.release(i)
     return outs
 
 

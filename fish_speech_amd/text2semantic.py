@@ -108,10 +108,12 @@ def generate_long(*, model, device: Union[str, torch.device], decode_one_token: 
                   repetition_penalty: float = 1.1, temperature: float = 1.0, compile: bool = False,
                   iterative_prompt: bool = True, chunk_length: int = 512,
                   prompt_text: Optional[Union[str, List[str]]] = None,
-                  prompt_tokens: Optional[Union[torch.Tensor, List[torch.Tensor]]] = None
-                  ) -> Iterator[GenerateResponse]:
+                  prompt_tokens: Optional[Union[torch.Tensor, List[torch.Tensor]]] = None,
+                  reuse_prefix_kv: bool = True) -> Iterator[GenerateResponse]:
     """Drop-in for generate_long (inference.py:523-733); `repetition_penalty`, `compile`, `iterative_prompt` are
-    accepted and unused exactly as upstream."""
+    accepted and unused exactly as upstream.  `reuse_prefix_kv` (extension): every chunk's prompt repeats the
+    conversation so far; upstream re-prefills all of it (inference.py:620-688), here the K/V of the shared prefix stay
+    in the slot and only the new columns are prefilled -- bit-identical results (tests/test_stream_gpu.py)."""
     assert 0 < top_p <= 1, "top_p must be in (0, 1]"
     assert 0 < temperature < 2, "temperature must be in (0, 2)"
     use_prompt = bool(prompt_text) and bool(prompt_tokens)
@@ -139,13 +141,16 @@ def generate_long(*, model, device: Union[str, torch.device], decode_one_token: 
                 raise ValueError(f"Prompt is too long: {encoded.size(1)} > {max_length - 2048}")
             encoded = encoded.to(device=device)
             T = encoded.size(1)
+            extra = {"reuse_prefix": True} if (reuse_prefix_kv and generate is _default_generate) else {}
             y = generate(model=model, prompt=encoded, max_new_tokens=max_new_tokens, audio_masks=audio_masks,
                          audio_parts=audio_parts, decode_one_token=decode_one_token, temperature=temperature,
-                         top_p=top_p, top_k=top_k)
+                         top_p=top_p, top_k=top_k, **extra)
             codes = y[1:, T:-1].clone()               # drops the <|im_end|> frame (inference.py:708)
             assert (codes >= 0).all(), f"Negative code found: {codes}"
             history.append(Message(role="assistant", parts=[VQPart(codes=codes.cpu())], modality="voice"))
             yield GenerateResponse(action="sample", codes=codes, text=chunk)
+        if reuse_prefix_kv and hasattr(model, "release") and generate is _default_generate:
+            model.release(0)   # the next sample starts a new conversation
         yield GenerateResponse(action="next")
 
 

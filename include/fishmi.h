@@ -100,6 +100,15 @@ int fmi_dualar_prefill(fmi_dualar* h, int n, const int32_t* slot_ids, const int3
                        const int32_t* lens, const int32_t* max_new, const fmi_sampling* samp,
                        void* stream);
 
+/* Prefix-KV reuse across the text chunks of generate_long (the reference re-prefills the whole conversation for every
+ * chunk, inference.py:620-688): the slots still hold the K/V of positions [0, pos0[i]) from an earlier prefill of the
+ * SAME tokens (not released since); only the lens[i] new columns in tokens_dev are run, at positions pos0[i].., with
+ * attention over the cached prefix.  Bit-identical to fmi_dualar_prefill of the whole prompt as long as the reused
+ * positions were themselves written by a prefill (the suffix rows are forced through the prefill kernels). */
+int fmi_dualar_prefill_resume(fmi_dualar* h, int n, const int32_t* slot_ids, const int32_t* tokens_dev,
+                              const int32_t* lens, const int32_t* pos0, const int32_t* max_new,
+                              const fmi_sampling* samp, void* stream);
+
 /* Advance the given slots by n_frames frames (one hipGraph replay per frame; no host sync
  * inside).  Replaces decode_n_tokens (inference.py:184-238) for a batch. A slot that emitted
  * <|im_end|> or exhausted its reservation stops advancing. */

@@ -187,6 +187,55 @@ def test_generate_long_end_to_end_on_the_gpu():
     assert torch.equal(p1[:, : prompts[0].shape[1]], prompts[0])          # the first prompt is a prefix of the second
 
 
+def test_generate_long_prefix_kv_reuse_is_bit_identical_to_re_prefill():
+    """8f #1: every chunk of generate_long repeats the conversation so far; upstream re-prefills all of it
+    (inference.py:620-688).  With prefix-KV reuse the slot keeps its pages and only the new columns are prefilled.
+    A 3-chunk conversation with a voice-clone system prompt, reuse on vs off: identical codes for every chunk
+    (bit-identical K/V: the reused positions were written by a prefill, the suffix rows run through the same
+    kernels a full prefill uses), and most prompt rows are not recomputed."""
+    import itertools
+    import time
+
+    from fish_speech_amd import text2semantic as T2S
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR
+    from oracle import dual_ar as O
+    from oracle.fake_tokenizer import ByteTokenizer
+
+    tok = ByteTokenizer()
+    cfg = O.DualARConfig(vocab_size=tok.vocab_size + 4, dim=128, n_layer=2, n_head=4, n_local_heads=2, head_dim=32,
+                         intermediate_size=256, max_seq_len=2048 + 1024, codebook_size=4096, num_codebooks=10,
+                         semantic_begin_id=tok.semantic_begin_id, semantic_end_id=tok.semantic_end_id,
+                         im_end_id=tok.get_token_id("<|im_end|>"), n_fast_layer=2)
+    state = O.make_synthetic_state(cfg, seed=5, head_gain=4.0)
+    model = MiDualAR.from_state_dict(DualARConfig.from_any(cfg), state, device=DEV, im_end_id=cfg.im_end_id)
+    model.tokenizer = tok
+    model.setup_caches(1, cfg.max_seq_len)
+    ref_codes = torch.randint(0, 4096, (10, 120), generator=torch.Generator().manual_seed(3))
+    text = ("<|speaker:0|>First chunk of text, long enough.<|speaker:1|>Second chunk, another speaker talks."
+            "<|speaker:0|>And a third turn to finish the conversation.")
+    kw = dict(model=model, device=DEV, text=text, max_new_tokens=14, chunk_length=40, temperature=0.8, top_p=0.8,
+              top_k=20, prompt_text=["reference transcript"], prompt_tokens=[ref_codes])
+
+    def run(reuse):
+        torch.manual_seed(7)
+        model._seed_counter = itertools.count()
+        model.prefilled_rows = model.reused_rows = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = list(T2S.generate_long(reuse_prefix_kv=reuse, **kw))
+        torch.cuda.synchronize()
+        return out, model.prefilled_rows, model.reused_rows, time.perf_counter() - t0
+
+    plain, rows_plain, reused_plain, t_plain = run(False)
+    reuse, rows_reuse, reused, t_reuse = run(True)
+    assert [r.action for r in plain] == ["sample"] * 3 + ["next"] == [r.action for r in reuse]
+    for a, b in zip(plain[:3], reuse[:3]):
+        assert torch.equal(a.codes.cpu(), b.codes.cpu())
+    print(f"prefix-KV reuse over 3 chunks: prompt rows prefilled {rows_plain} -> {rows_reuse} ({reused} reused); "
+          f"wall {t_plain * 1e3:.1f} -> {t_reuse * 1e3:.1f} ms")
+    assert reused_plain == 0 and reused > 0.5 * rows_plain and rows_reuse + reused == rows_plain
+
+
 def test_from_pretrained_reads_an_s2_style_checkpoint_directory(tmp_path, monkeypatch):
     """SURVEY.md row a17 end to end: config.json of model_type fish_qwen3_omni, sharded safetensors with the HF
     tensor names (text_model.model.* / audio_decoder.*) and separate wq/wk/wv (Attention.load_hook,
