@@ -265,8 +265,8 @@ class MiDAC:
         norms and residual adds stay fp32 (torch's type promotion gives fp32 there too, parameters being fp32).
         Outside autocast the configured precision applies (default: fp32-class three-plane arithmetic)."""
         planes = self._planes
-        if torch.is_autocast_enabled():
-            if torch.get_autocast_gpu_dtype() != torch.bfloat16:
+        if torch.is_autocast_enabled("cuda"):
+            if torch.get_autocast_dtype("cuda") != torch.bfloat16:
                 raise _lib.FishmiError("MiDAC supports autocast(dtype=torch.bfloat16) only (the engine's --half fp16 mode "
                                        "is not implemented)")
             planes = 1

@@ -1,0 +1,133 @@
+"""Engine-level streaming (reference: fish_speech/inference_engine/__init__.py:28-140 `TTSInferenceEngine.inference`,
+utils.py `InferenceResult` / `wav_chunk_header`, tools/server/inference.py:12-45).
+
+The reference engine streams at TEXT-chunk granularity: one `InferenceResult("segment")` per `GenerateResponse` of
+`generate_long`, each decoded whole by `decode_vq_tokens`.  `StreamingTTSEngine.inference` keeps that protocol --
+"header" (wav header bytes) when streaming, "segment"s, one "final" with the whole utterance, "error" on failure --
+but a segment leaves every `chunk_frames` frames (after `first_chunk_frames` for the first one): the Dual-AR frame
+loop and the incremental codec decode of `stream.generate_stream` are interleaved, so first audio needs
+`first_chunk_frames` frames instead of a whole text chunk.  The concatenation of the segments IS the final audio, and
+equals `from_indices` over the codes the offline path generates (tests/test_stream_gpu.py)."""
+from __future__ import annotations
+
+import io
+import wave
+from dataclasses import dataclass
+from typing import Iterator, List, Literal, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .prompt import Conversation, Message, TextPart, VQPart
+from .stream import generate_stream
+from .text2semantic import _system_message, group_turns_into_batches, split_text_by_speaker
+
+AMPLITUDE = 32768   # tools/server/inference.py:9
+
+
+@dataclass
+class InferenceResult:                       # inference_engine/utils.py:9-13
+    code: Literal["header", "segment", "error", "final"]
+    audio: Optional[Tuple[int, np.ndarray]]
+    error: Optional[Exception]
+
+
+def wav_chunk_header(sample_rate: int = 44100, bit_depth: int = 16, channels: int = 1) -> bytes:
+    """An empty wav file = the header a streaming client prepends (inference_engine/utils.py:16-29)."""
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as f:
+        f.setnchannels(channels)
+        f.setsampwidth(bit_depth // 8)
+        f.setframerate(sample_rate)
+    return buf.getvalue()
+
+
+@dataclass
+class TTSRequest:
+    """The fields of ServeTTSRequest (fish_speech/utils/schema.py) the engine reads."""
+    text: str
+    streaming: bool = False
+    max_new_tokens: int = 1024
+    top_p: float = 0.8
+    temperature: float = 0.8
+    chunk_length: int = 200
+    seed: Optional[int] = None
+    prompt_texts: Sequence[str] = ()
+    prompt_tokens: Sequence[torch.Tensor] = ()      # (num_codebooks, n) codes of the references (VQManager.encode_reference)
+    top_k: int = 30
+    first_chunk_frames: int = 8
+    chunk_frames: int = 32
+
+
+class StreamingTTSEngine:
+    def __init__(self, model, codec, precision=torch.bfloat16):
+        self.model, self.decoder_model, self.precision = model, codec, precision
+
+    @torch.no_grad()
+    def inference(self, req: TTSRequest) -> Iterator[InferenceResult]:
+        model, codec = self.model, self.decoder_model
+        sample_rate = codec.sample_rate
+        try:
+            if req.streaming:
+                yield InferenceResult("header", (sample_rate, np.array(wav_chunk_header(sample_rate=sample_rate))), None)
+            use_prompt = bool(req.prompt_texts) and bool(req.prompt_tokens)
+            system = _system_message(list(req.prompt_texts) if use_prompt else None,
+                                     [c.cpu() for c in req.prompt_tokens] if use_prompt else None)
+            turns = split_text_by_speaker(req.text)
+            chunks = group_turns_into_batches(turns, max_speakers=5, max_bytes=req.chunk_length) if turns else [req.text]
+            history = Conversation([system])
+            segments: List[np.ndarray] = []
+            for ci, chunk in enumerate(chunks):
+                history.append(Message(role="user", parts=[TextPart(text=chunk)]))
+                asking = history.copy()
+                asking.append(Message(role="assistant", parts=[], modality="voice", add_im_end=False))
+                prompt, _, _ = asking.encode_for_inference(model.tokenizer, num_codebooks=model.config.num_codebooks)
+                if prompt.size(1) > model.config.max_seq_len - 2048:    # text2semantic/inference.py:658-661
+                    raise ValueError(f"Prompt is too long: {prompt.size(1)} > {model.config.max_seq_len - 2048}")
+                seeds = None if req.seed is None else [int(req.seed) + ci]
+                codes_parts = []
+                # the engine decodes under autocast(self.precision) (inference_engine/__init__.py:183-186)
+                with torch.autocast("cuda", dtype=self.precision, enabled=self.precision is not None):
+                    for ch in generate_stream(model=model, codec=codec, prompts=[prompt],
+                                              max_new_tokens=req.max_new_tokens, first_chunk_frames=req.first_chunk_frames,
+                                              chunk_frames=req.chunk_frames, seeds=seeds, temperature=req.temperature,
+                                              top_p=req.top_p, top_k=req.top_k):
+                        n = ch.valid_frames[0]
+                        if n <= 0:
+                            continue
+                        seg = ch.audio[0, 0, : n * codec.frame_length].float().cpu().numpy()
+                        codes_parts.append(ch.codes[0, :, :n].cpu())
+                        segments.append(seg)
+                        if req.streaming:
+                            yield InferenceResult("segment", (sample_rate, seg), None)
+                if codes_parts:
+                    history.append(Message(role="assistant", parts=[VQPart(codes=torch.cat(codes_parts, dim=1))],
+                                           modality="voice"))
+            if not segments:
+                yield InferenceResult("error", None, RuntimeError("No audio generated, please check the input text."))
+            else:
+                yield InferenceResult("final", (sample_rate, np.concatenate(segments, axis=0)), None)
+        except Exception as e:   # the reference reports worker errors as a result, not as a raise (__init__.py:88-98)
+            yield InferenceResult("error", None, e)
+
+
+def inference_wrapper(req: TTSRequest, engine: StreamingTTSEngine):
+    """tools/server/inference.py:12-45: the byte stream the HTTP endpoint sends."""
+    count = 0
+    for result in engine.inference(req):
+        if result.code == "header":
+            if isinstance(result.audio, tuple):
+                yield result.audio[1]
+        elif result.code == "error":
+            raise RuntimeError(str(result.error))
+        elif result.code == "segment":
+            count += 1
+            if isinstance(result.audio, tuple):
+                yield (result.audio[1] * AMPLITUDE).astype(np.int16).tobytes()
+        elif result.code == "final":
+            count += 1
+            if isinstance(result.audio, tuple):
+                yield result.audio[1]
+            return
+    if count == 0:
+        raise RuntimeError("No audio generated, please check the input text.")

@@ -331,3 +331,100 @@ def test_continuous_batching_queue_is_schedule_invariant(tiny_model):
         assert torch.equal(one[i], alone[i]), i
     lengths = {int(a.shape[1] - p.shape[1]) for a, p in zip(alone, prompts)}
     assert stats["frames_run"] >= max(lengths) - 1
+
+
+# ------------------------------------------------------------------------------- 8f #3 / #4: server batch helpers, engine
+
+
+def test_server_batch_encode_and_decode_helpers(small_codec):
+    """tools/server/model_utils.py:15-86 over MiDAC: batch_encode of ragged wav byte strings == per-item encode;
+    batch_vqgan_decode (micro-batches of 8, right padding) == per-item from_indices, trimmed to T_i frames."""
+    import io
+
+    import numpy as np
+    from scipy.io import wavfile
+
+    from fish_speech_amd import server_utils as SU
+
+    cfg, _, codec = small_codec
+    fl = cfg.frame_length
+    g = torch.Generator().manual_seed(4)
+    wavs = [0.2 * torch.randn(n, generator=g) for n in (3 * fl + 17, fl - 5, 5 * fl)]
+    blobs = []
+    for w in wavs:
+        buf = io.BytesIO()
+        wavfile.write(buf, codec.sample_rate, w.numpy().astype(np.float32))
+        blobs.append(buf.getvalue())
+    feats = SU.batch_encode(codec, blobs)
+    assert [f.shape[-1] for f in feats] == [4, 1, 5]
+    for w, f in zip(wavs, feats):
+        one, n = codec.encode(w.view(1, 1, -1).to(DEV), torch.tensor([w.numel()], device=DEV))
+        assert torch.equal(one[0, :, : int(n[0])].cpu(), f)
+    assert SU.cached_vqgan_batch_encode(codec, blobs) is SU.cached_vqgan_batch_encode(codec, blobs)
+    many = [D.make_codes(cfg, 1, 2 + (i % 5), seed=70 + i)[0] for i in range(11)]      # two micro-batches
+    outs = SU.batch_vqgan_decode(codec, many)
+    for f, o in zip(many, outs):
+        want = codec.from_indices(f[None].clone().to(DEV))[0].cpu().numpy()
+        assert o.shape == (1, f.shape[-1] * fl) and float(np.sqrt(np.mean((o - want) ** 2))) <= 1e-5
+
+
+def test_engine_streaming_segments_equal_final_equal_offline():
+    """8f #4 as tested code: the engine-shaped generator (header / segment / final like
+    inference_engine/__init__.py:73-140) streams at frame granularity; the concatenated segments are the final audio,
+    streaming and non-streaming requests give the same audio, and a one-chunk request equals the offline path
+    (generate -> codes[1:, T:-1] -> from_indices under the engine's autocast)."""
+    import numpy as np
+
+    from fish_speech_amd.dac import DacConfig, MiDAC
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR, generate
+    from fish_speech_amd.engine import InferenceResult, StreamingTTSEngine, TTSRequest, inference_wrapper, wav_chunk_header
+    from fish_speech_amd.prompt import Conversation, Message, TextPart
+    from fish_speech_amd.text2semantic import _system_message
+    from oracle import dual_ar as O
+    from oracle.fake_tokenizer import ByteTokenizer
+
+    tok = ByteTokenizer()
+    cfg = O.DualARConfig(vocab_size=tok.vocab_size + 4, dim=128, n_layer=2, n_head=4, n_local_heads=2, head_dim=32,
+                         intermediate_size=256, max_seq_len=2048 + 512, codebook_size=4096, num_codebooks=10,
+                         semantic_begin_id=tok.semantic_begin_id, semantic_end_id=tok.semantic_end_id,
+                         im_end_id=tok.get_token_id("<|im_end|>"), n_fast_layer=2)
+    model = MiDualAR.from_state_dict(DualARConfig.from_any(cfg), O.make_synthetic_state(cfg, seed=5, head_gain=4.0),
+                                     device=DEV, im_end_id=cfg.im_end_id)
+    model.tokenizer = tok
+    model.setup_caches(1, cfg.max_seq_len)
+    ccfg = D.DacConfig(encoder_dim=8, decoder_dim=96, n_codebooks=9, codebook_size=1024, semantic_codebook_size=4096,
+                       tf_layers=2, tf_window=8, enc_tf_layers=2, enc_tf_window=16)
+    codec = MiDAC.from_state_dict(DacConfig.from_any(ccfg), D.make_synthetic_state(ccfg, seed=2), device=DEV)
+    engine = StreamingTTSEngine(model, codec)
+    text = "<|speaker:0|>First chunk of text.<|speaker:1|>Second chunk, another speaker."
+    base = dict(text=text, max_new_tokens=21, chunk_length=30, seed=77, first_chunk_frames=3, chunk_frames=5)
+
+    res = list(engine.inference(TTSRequest(streaming=True, **base)))
+    assert [r.code for r in res][0] == "header" and res[-1].code == "final" and all(r.error is None for r in res)
+    segs = [r for r in res if r.code == "segment"]
+    assert len(segs) >= 4
+    hdr = res[0].audio[1].tobytes() if hasattr(res[0].audio[1], "tobytes") else bytes(res[0].audio[1])
+    assert wav_chunk_header(sample_rate=codec.sample_rate)[:4] == b"RIFF" and len(wav_chunk_header()) == 44
+    assert int.from_bytes(wav_chunk_header(sample_rate=codec.sample_rate)[24:28], "little") == codec.sample_rate
+    final = res[-1].audio[1]
+    assert np.array_equal(np.concatenate([s.audio[1] for s in segs]), final)
+    quiet = list(engine.inference(TTSRequest(streaming=False, **base)))
+    assert [r.code for r in quiet] == ["final"] and np.array_equal(quiet[0].audio[1], final)
+    out = list(inference_wrapper(TTSRequest(streaming=True, **base), engine))
+    assert isinstance(out[0], (bytes, np.ndarray)) and all(isinstance(b, bytes) for b in out[1:-1])
+    assert sum(len(b) for b in out[1:-1]) == 2 * final.size          # int16 segments
+
+    # one text chunk == the offline path on the same prompt and seed
+    one = "<|speaker:0|>Just one chunk."
+    r1 = list(engine.inference(TTSRequest(text=one, max_new_tokens=21, chunk_length=200, seed=5)))
+    conv = Conversation([_system_message(None, None), Message(role="user", parts=[TextPart(text=one)]),
+                         Message(role="assistant", parts=[], modality="voice", add_im_end=False)])
+    prompt, _, _ = conv.encode_for_inference(tok, num_codebooks=10)
+    y = generate(model=model, prompt=prompt, max_new_tokens=21, seed=5, temperature=0.8, top_p=0.8, top_k=30)
+    codes = y[1:, prompt.shape[1]:-1]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        want = codec.from_indices(codes[None].clone().to(DEV))[0, 0].float().cpu().numpy()
+    assert r1[-1].code == "final" and np.array_equal(r1[-1].audio[1], want)
+    bad = list(engine.inference(TTSRequest(text=one, max_new_tokens=21, top_p=0.8, prompt_texts=["x"],
+                                           prompt_tokens=[torch.zeros(3, 4, dtype=torch.long)])))
+    assert bad[-1].code == "error" and isinstance(bad[-1].error, Exception)
