@@ -41,8 +41,7 @@ def main(input_path, output_path, config_name, checkpoint_path, device):
     from .dac import MiDAC
 
     dev = "cuda:0" if device == "cuda" else device
-    state = torch.load(checkpoint_path, map_location="cpu", mmap=True, weights_only=True)
-    model = MiDAC(device=dev).load_state_dict(state)
+    model = MiDAC.from_checkpoint(checkpoint_path, device=dev)
     if input_path.suffix == ".npy":
         indices = torch.from_numpy(np.load(input_path)).to(dev).long()
         assert indices.ndim == 2, f"Expected 2D indices, got {indices.ndim}"

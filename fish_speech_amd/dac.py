@@ -46,6 +46,36 @@ class DacConfig:
         kw = {f: getattr(cfg, f) for f in cls.__dataclass_fields__ if hasattr(cfg, f)}
         return cls(**kw)
 
+    @classmethod
+    def from_state_dict(cls, folded: Dict[str, torch.Tensor], **overrides) -> "DacConfig":
+        """Architecture read off the tensor shapes of a (weight-norm-folded) codec checkpoint; for the released
+        codec.pth this reproduces modded_dac_vq.yaml.  The attention windows are not visible in the weights: they
+        keep the yaml's values unless overridden."""
+        def count(prefix, suffix):
+            n = 0
+            while f"{prefix}{n}{suffix}" in folded:
+                n += 1
+            return n
+
+        enc = folded["encoder.block.0.conv.weight"].shape[0]
+        enc_rates = tuple(folded[f"encoder.block.{i + 1}.block.4.conv.weight"].shape[2] // 2 for i in range(4))
+        dec = folded["decoder.model.0.conv.weight"].shape[0]
+        dec_rates = tuple(folded[f"decoder.model.{i + 1}.block.1.conv.weight"].shape[2] // 2 for i in range(4))
+        L = folded["decoder.model.0.conv.weight"].shape[1]
+        cb = folded["quantizer.quantizer.quantizers.0.codebook.weight"]
+        kw = dict(encoder_dim=enc, encoder_rates=enc_rates, decoder_dim=dec, decoder_rates=dec_rates,
+                  n_codebooks=count("quantizer.quantizer.quantizers.", ".codebook.weight"), codebook_size=cb.shape[0],
+                  codebook_dim=cb.shape[1],
+                  semantic_codebook_size=folded["quantizer.semantic_quantizer.quantizers.0.codebook.weight"].shape[0],
+                  downsample=tuple(folded[f"quantizer.downsample.{i}.0.conv.weight"].shape[2]
+                                   for i in range(count("quantizer.downsample.", ".0.conv.weight"))),
+                  tf_layers=count("quantizer.pre_module.layers.", ".attention.wqkv.weight"),
+                  enc_tf_layers=count("encoder.block.4.block.5.layers.", ".attention.wqkv.weight"))
+        if kw["tf_layers"]:
+            kw["tf_ffn_mult"] = folded["quantizer.pre_module.layers.0.feed_forward.w1.weight"].shape[0] // L
+        kw.update(overrides)
+        return cls(**kw)
+
     @property
     def latent_dim(self) -> int:
         return self.encoder_dim * 2 ** len(self.encoder_rates)
@@ -281,6 +311,18 @@ class MiDAC:
     @classmethod
     def from_state_dict(cls, config, state, device="cuda:0") -> "MiDAC":
         return cls(config, device=device).load_state_dict(state)
+
+    @classmethod
+    def from_checkpoint(cls, path, device="cuda:0", **config_overrides) -> "MiDAC":
+        """codec.pth loader of the CLIs (dac/inference.py:29-42: optional `state_dict` wrapper, `generator.` prefix
+        stripped); the architecture is read off the tensor shapes."""
+        state = torch.load(str(path), map_location="cpu", mmap=True, weights_only=True)
+        if "state_dict" in state:
+            state = state["state_dict"]
+        if any("generator" in k for k in state):
+            state = {k.replace("generator.", ""): v for k, v in state.items() if "generator." in k}
+        folded = fold_weight_norm(state)
+        return cls(DacConfig.from_state_dict(folded, **config_overrides), device=device).load_folded_state(folded)
 
     # ---- DAC.encode (modded_dac.py:874-923)
     @torch.no_grad()

@@ -246,8 +246,7 @@ def _cli():
             nonlocal codec
             if codec is None:
                 from .dac import MiDAC
-                state = torch.load(checkpoint_path / "codec.pth", map_location="cpu", mmap=True, weights_only=True)
-                codec = MiDAC(device=device).load_state_dict(state)
+                codec = MiDAC.from_checkpoint(checkpoint_path / "codec.pth", device=device)
             return codec
 
         prompt_list = None
@@ -255,8 +254,8 @@ def _cli():
             from .codec_cli import _load_wav
             prompt_list = []
             for p in prompt_audio:
-                wav = _load_wav(p, get_codec().sample_rate).to(device)
-                idx, lens = get_codec().encode(wav[None], torch.tensor([wav.shape[-1]], device=device))
+                wav = _load_wav(p, get_codec().sample_rate).to(device)          # (1, 1, n)
+                idx, lens = get_codec().encode(wav, torch.tensor([wav.shape[-1]], device=device))
                 prompt_list.append(idx[0, :, : int(lens[0])].cpu())
         elif prompt_tokens:
             prompt_list = [torch.from_numpy(np.load(p)) for p in prompt_tokens]

@@ -1,0 +1,162 @@
+"""CLI surface on the GPU (row a27): the codec CLI (dac/inference.py:50-122 flags) and the text2semantic CLI's
+--prompt-audio / --prompt-tokens / --output path (text2semantic/inference.py:802-960), driven through click with small
+synthetic checkpoints written in the reference's on-disk formats (codec.pth with weight-norm keys; an S2-style
+checkpoint directory)."""
+import json
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+from click.testing import CliRunner
+
+from oracle import dac as D
+from oracle import dual_ar as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _write_wav(path, sr, seconds, seed, dtype="int16", channels=1):
+    from scipy.io import wavfile
+
+    g = np.random.default_rng(seed)
+    n = int(sr * seconds)
+    t = np.arange(n) / sr
+    x = 0.3 * np.sin(2 * np.pi * 220 * t) + 0.02 * g.standard_normal(n)
+    if channels == 2:
+        x = np.stack([x, 0.5 * x], axis=1)
+    if dtype == "int16":
+        x = (x * 32767).astype(np.int16)
+    else:
+        x = x.astype(np.float32)
+    wavfile.write(str(path), sr, x)
+
+
+def _codec_ckpt(tmp_path, n_codebooks=3, codebook_size=64, semantic=128):
+    cfg = D.DacConfig(encoder_dim=8, decoder_dim=96, n_codebooks=n_codebooks, codebook_size=codebook_size,
+                      semantic_codebook_size=semantic, tf_layers=2, enc_tf_layers=2)    # yaml windows (128 / 512)
+    state = D.make_synthetic_state(cfg, seed=31)
+    path = tmp_path / "codec.pth"
+    torch.save({"state_dict": {"generator." + k: v for k, v in state.items()}}, str(path))   # dac/inference.py:29-42 wrapping
+    return cfg, state, path
+
+
+def test_codec_config_is_read_off_the_checkpoint(tmp_path):
+    from fish_speech_amd.dac import DacConfig, MiDAC, fold_weight_norm
+
+    cfg, state, path = _codec_ckpt(tmp_path)
+    got = DacConfig.from_state_dict(fold_weight_norm(state))
+    for f in ("encoder_dim", "decoder_dim", "n_codebooks", "codebook_size", "semantic_codebook_size", "codebook_dim",
+              "tf_layers", "enc_tf_layers", "tf_ffn_mult"):
+        assert getattr(got, f) == getattr(DacConfig.from_any(cfg), f), f
+    assert tuple(got.encoder_rates) == (2, 4, 8, 8) and tuple(got.decoder_rates) == (8, 8, 4, 2) and tuple(got.downsample) == (2, 2)
+    full = DacConfig.from_state_dict({k: torch.empty(v, device="meta") for k, v in
+                                      __import__("fish_speech_amd.dac", fromlist=["x"]).expected_state_shapes(DacConfig()).items()})
+    assert full == DacConfig()                                   # the yaml's architecture round-trips
+    codec = MiDAC.from_checkpoint(path, device=DEV)
+    codes = D.make_codes(cfg, 1, 4, seed=1)
+    assert torch.equal(codec.from_indices(codes.clone().to(DEV)),
+                       MiDAC.from_state_dict(DacConfig.from_any(cfg), state, device=DEV).from_indices(codes.clone().to(DEV)))
+
+
+def test_codec_cli_wav_to_codes_to_wav(tmp_path):
+    from scipy.io import wavfile
+
+    from fish_speech_amd.codec_cli import _load_wav, main
+    from fish_speech_amd.dac import MiDAC
+
+    cfg, state, ckpt = _codec_ckpt(tmp_path)
+    wav_in = tmp_path / "in.wav"
+    _write_wav(wav_in, 22050, 0.4, seed=1, channels=2)            # other rate + stereo: resample, mono mean
+    out = tmp_path / "fake.wav"
+    r = CliRunner().invoke(main, ["-i", str(wav_in), "-o", str(out), "--checkpoint-path", str(ckpt), "-d", "cuda"])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    codes = np.load(out.with_suffix(".npy"))
+    codec = MiDAC.from_checkpoint(ckpt, device=DEV)
+    audio = _load_wav(wav_in, codec.sample_rate).to(DEV)
+    want, lens = codec.encode(audio, torch.tensor([audio.shape[-1]], device=DEV))
+    assert codes.shape == (cfg.n_codebooks + 1, int(lens[0])) and np.array_equal(codes, want[0].cpu().numpy())
+    sr, y = wavfile.read(str(out))
+    assert sr == codec.sample_rate and y.shape[0] == codes.shape[1] * cfg.frame_length
+    out2 = tmp_path / "again.wav"
+    r = CliRunner().invoke(main, ["-i", str(out.with_suffix(".npy")), "-o", str(out2), "--checkpoint-path", str(ckpt), "-d", "cuda"])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    assert np.array_equal(wavfile.read(str(out2))[1], y)
+
+
+def _s2_checkpoint(tmp_path, monkeypatch):
+    from safetensors.torch import save_file
+
+    from oracle.fake_tokenizer import ByteTokenizer
+
+    tok = ByteTokenizer()
+    cfg = O.DualARConfig(vocab_size=tok.vocab_size + 4, dim=128, n_layer=2, n_head=4, n_local_heads=2, head_dim=32,
+                         intermediate_size=256, max_seq_len=4096, codebook_size=4096, num_codebooks=10,
+                         semantic_begin_id=tok.semantic_begin_id, semantic_end_id=tok.semantic_end_id,
+                         im_end_id=tok.get_token_id("<|im_end|>"), n_fast_layer=2, rope_base=1000000.0, norm_eps=1e-6)
+    state = O.make_synthetic_state(cfg, seed=21, head_gain=4.0)
+    hf = {}
+    for k, v in state.items():
+        if k.startswith("fast_"):
+            name = "audio_decoder." + k[len("fast_"):]
+        elif k.startswith("codebook_embeddings."):
+            name = "audio_decoder." + k
+        else:
+            name = "text_model.model." + k
+        hf[name] = v.contiguous()
+    save_file(hf, str(tmp_path / "model.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps({
+        "model_type": "fish_qwen3_omni", "semantic_start_token_id": 0, "semantic_end_token_id": 0,
+        "text_config": {"vocab_size": cfg.vocab_size, "n_layer": 2, "n_head": 4, "n_local_heads": 2, "head_dim": 32,
+                        "dim": 128, "intermediate_size": 256, "rope_base": 1000000, "norm_eps": 1e-6,
+                        "max_seq_len": 4096, "attention_qk_norm": True},
+        "audio_decoder_config": {"vocab_size": 4096, "num_codebooks": 10, "n_layer": 2}}))
+
+    class FishTokenizer:
+        @classmethod
+        def from_pretrained(cls, path):
+            return tok
+
+    pkg, mod = types.ModuleType("fish_speech"), types.ModuleType("fish_speech.tokenizer")
+    mod.FishTokenizer = FishTokenizer
+    pkg.tokenizer = mod
+    monkeypatch.setitem(sys.modules, "fish_speech", pkg)
+    monkeypatch.setitem(sys.modules, "fish_speech.tokenizer", mod)
+    return cfg, tok
+
+
+def test_text2semantic_cli_with_prompt_audio_and_wav_output(tmp_path, monkeypatch):
+    """--prompt-text + --prompt-audio (encoded by the codec from the checkpoint directory, inference.py:891-901),
+    codes_0.npy in --output-dir, a wav with --output; --prompt-tokens gives the same codes as --prompt-audio when fed
+    the codes that audio encodes to."""
+    from scipy.io import wavfile
+
+    from fish_speech_amd.codec_cli import _load_wav
+    from fish_speech_amd.dac import MiDAC
+    from fish_speech_amd.text2semantic import _cli
+
+    cfg, tok = _s2_checkpoint(tmp_path, monkeypatch)
+    ccfg, _, _ = _codec_ckpt(tmp_path, n_codebooks=9, codebook_size=1024, semantic=4096)
+    ref = tmp_path / "ref.wav"
+    _write_wav(ref, 44100, 0.25, seed=2, dtype="float32")
+    outdir = tmp_path / "out"
+    args = ["--text", "<|speaker:0|>Hello there.", "--prompt-text", "a reference", "--checkpoint-path", str(tmp_path),
+            "--device", "cuda:0", "--max-new-tokens", "9", "--seed", "3", "--output-dir", str(outdir)]
+    r = CliRunner().invoke(_cli(), args + ["--prompt-audio", str(ref), "--output", str(tmp_path / "tts.wav")])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    codes = np.load(outdir / "codes_0.npy")
+    assert codes.shape[0] == 10 and 1 <= codes.shape[1] <= 8 and codes.min() >= 0 and codes.max() < 4096
+    sr, y = wavfile.read(str(tmp_path / "tts.wav"))
+    assert sr == 44100 and y.shape[0] == codes.shape[1] * ccfg.frame_length
+    codec = MiDAC.from_checkpoint(tmp_path / "codec.pth", device=DEV)
+    wav = _load_wav(ref, codec.sample_rate).to(DEV)
+    idx, lens = codec.encode(wav, torch.tensor([wav.shape[-1]], device=DEV))
+    np.save(tmp_path / "ref.npy", idx[0, :, : int(lens[0])].cpu().numpy())
+    outdir2 = tmp_path / "out2"
+    r = CliRunner().invoke(_cli(), args[:-1] + [str(outdir2), "--prompt-tokens", str(tmp_path / "ref.npy")])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    assert np.array_equal(np.load(outdir2 / "codes_0.npy"), codes)
+    r = CliRunner().invoke(_cli(), args + ["--half"])
+    assert r.exit_code != 0                                                    # fp16 is refused, not silently bf16
