@@ -1922,8 +1922,9 @@ struct SmallShared {
   int sel[4];
   int cand_idx[64];
   uint32_t cand_key[64];
-  float s_val[64];
+  __attribute__((aligned(16))) float s_val[64];
   int s_idx[64];
+  uint32_t wc[4][64];   // per wave: its k candidates as key << 16 | ~index, then sorted descending
 };
 
 // suffix[b] = sum_{j >= b} hist[j] evaluated by wave 0; returns via sel[o], sel[o+1] the bin where the
@@ -2054,8 +2055,13 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   const float sumexp = sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3];
   if (a.dbg_stop == 3) return;
 
-  // ---- k-th largest key: radix-4 descent over the 16 key bits, counts from registers
-  // thr = max T with count(key >= T) >= k
+  // ---- top-k without block-wide rounds.  Every wave picks the k largest of ITS keys by a radix-4 descent whose
+  // counts meet inside the wave (DPP reductions, no LDS, no barrier), compacts them in index order (ties on the
+  // k-th key: lowest indices first), sorts them with a 64-lane bitonic network on the 32-bit word
+  // key << 16 | ~index (unique, and "larger word" == "larger logit, then lower index": the reference's stable
+  // descending sort); wave 0 then merges the four sorted lists pairwise (max of one list against the reverse of the
+  // other is bitonic and holds the 64 largest of both: six more stages sort it).  One barrier in total; lane r of
+  // wave 0 ends up with the rank-r candidate.
   uint32_t thr = 0;
 #pragma unroll 1
   for (int step = 0; step < 8; ++step) {
@@ -2068,27 +2074,12 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
       n2 += kr[j] >= c2;
       n3 += kr[j] >= c3;
     }
-    int packed = n1 | (n2 << 10);  // each count <= 17 per thread, <= 1088 per wave: 10 bits are not enough
-    // (pack only two 16-bit fields)
-    packed = n1 | (n2 << 16);
-    packed = wave_sum_dpp_i(packed);
-    n3 = wave_sum_dpp_i(n3);
-    const int par = step & 1;
-    if (lane == 0) {
-      sh.hist[par * 16 + wave * 2] = (uint32_t)packed;
-      sh.hist[par * 16 + wave * 2 + 1] = (uint32_t)n3;
-    }
-    __syncthreads();
-    uint32_t tp = 0, t3 = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      tp += sh.hist[par * 16 + w * 2];
-      t3 += sh.hist[par * 16 + w * 2 + 1];
-    }
-    const uint32_t t1 = tp & 0xffff, t2 = tp >> 16;
-    if (t3 >= (uint32_t)k) thr = c3;
-    else if (t2 >= (uint32_t)k) thr = c2;
-    else if (t1 >= (uint32_t)k) thr = c1;
+    const int tp = wave_sum_dpp_i(n1 | (n2 << 16));   // each count <= 17 * 64 = 1088
+    const int t3 = wave_sum_dpp_i(n3);
+    const int t1 = tp & 0xffff, t2 = (int)((uint32_t)tp >> 16);
+    if (t3 >= k) thr = c3;
+    else if (t2 >= k) thr = c2;
+    else if (t1 >= k) thr = c1;
   }
   int my_gt = 0, my_eq = 0;
 #pragma unroll
@@ -2097,8 +2088,6 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     my_eq += (kr[j] == thr) && (thr != 0);
   }
   if (a.dbg_stop == 4) return;
-
-  // ---- collect the k candidates in index order
   int inc_gt = my_gt, inc_eq = my_eq;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -2108,66 +2097,76 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
       inc_eq += e;
     }
   }
-  if (lane == 63) {
-    sh.wcnt_gt[wave] = inc_gt;
-    sh.wcnt_eq[wave] = inc_eq;
-  }
-  __syncthreads();
-  int off_gt = inc_gt - my_gt, off_eq = inc_eq - my_eq;
-  for (int w = 0; w < wave; ++w) {
-    off_gt += sh.wcnt_gt[w];
-    off_eq += sh.wcnt_eq[w];
-  }
-  const int c_gt = sh.wcnt_gt[0] + sh.wcnt_gt[1] + sh.wcnt_gt[2] + sh.wcnt_gt[3];
+  const int c_gt = __builtin_amdgcn_readlane(inc_gt, 63);     // this wave's keys above its threshold (< k)
   const int need_eq = k - c_gt;
+  int off_gt = inc_gt - my_gt, off_eq = inc_eq - my_eq;
+  uint32_t* wc = sh.wc[wave];
+  wc[lane] = 0;                                                 // word 0 = empty place (real words have key >= 0x7f)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
   for (int j = 0; j < SMALL_EPT; ++j) {
     const uint32_t key = kr[j];
+    const uint32_t word = (key << 16) | (uint32_t)(0xffff - (i0 + j));
     if (key > thr) {
-      sh.cand_idx[off_gt] = i0 + j;
-      sh.cand_key[off_gt] = key;
-      ++off_gt;
+      wc[off_gt++] = word;
     } else if (key == thr && thr != 0) {
-      if (off_eq < need_eq) {
-        sh.cand_idx[c_gt + off_eq] = i0 + j;
-        sh.cand_key[c_gt + off_eq] = key;
-      }
+      if (off_eq < need_eq) wc[c_gt + off_eq] = word;
       ++off_eq;
     }
-  }
-  __syncthreads();
-  if (wave != 0 || a.dbg_stop == 5) return;
-
-  // ---- wave 0: rank sort (key desc, index asc) with scalar broadcasts, sequential cumsum
-  const bool in = lane < k;
-  const uint32_t kc = in ? sh.cand_key[lane] : 0;
-  const int ic = in ? sh.cand_idx[lane] : 0x7fffffff;
-  int rank = 0;
-#pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kc, j);
-    const int ij = __builtin_amdgcn_readlane(ic, j);
-    rank += (j < k) && ((kj > kc) || (kj == kc && ij < ic));
-  }
-  // permute (value, row) into rank order: lane r receives the candidate whose rank is r
-  if (in) {
-    sh.s_val[rank] = __uint_as_float(kc);
-    sh.s_idx[rank] = ic;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const uint32_t ks = in ? __float_as_uint(sh.s_val[lane]) : 0;
+  uint32_t w = wc[lane];
+  // bitonic sort, descending over the 64 lanes
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)w, stride, 64);
+      const bool take_max = ((lane & stride) == 0) == ((lane & size) == 0);
+      w = take_max ? max(w, o) : min(w, o);
+    }
+  wc[lane] = w;
+  __syncthreads();
+  if (wave != 0 || a.dbg_stop == 5) return;
+  auto merge_desc = [&](uint32_t x, uint32_t y_rev) -> uint32_t {   // x sorted desc, y_rev = other list reversed
+    uint32_t m = max(x, y_rev);
+#pragma unroll
+    for (int stride = 32; stride > 0; stride >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)m, stride, 64);
+      m = ((lane & stride) == 0) ? max(m, o) : min(m, o);
+    }
+    return m;
+  };
+  const uint32_t m01 = merge_desc(w, sh.wc[1][63 - lane]);
+  const uint32_t m23 = merge_desc(sh.wc[2][lane], sh.wc[3][63 - lane]);
+  const uint32_t m23_rev = (uint32_t)__shfl((int)m23, 63 - lane, 64);
+  const uint32_t top = merge_desc(m01, m23_rev);
+
+  // ---- wave 0: lane r holds the rank-r candidate; sequential cumsum evaluated by every lane
+  const bool in = lane < k;
+  const uint32_t ks = top >> 16;
   const bf16_t vbits = (ks & 0x8000) ? (bf16_t)(ks & 0x7fff) : (bf16_t)(~ks & 0xffff);
   const float v = in ? bf2f(vbits) : -INFINITY;
-  const int row = in ? sh.s_idx[lane] : 0;
+  const int row = in ? (int)(0xffff - (top & 0xffff)) : 0;
   const int vid = a.ids ? a.ids[row] : row;
   const float p = in ? rbf(expf(v - vmax) / sumexp) : 0.f;
+  sh.s_val[lane] = p;                    // lanes >= k hold 0
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   float run = 0.f, cum = 0.f;  // torch.cumsum on bf16: fp32 running sum in rank order, outputs rounded
 #pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    run += rl_f(p, i);  // lanes >= k hold 0
-    if (lane == i) cum = rbf(run);
+  for (int i4 = 0; i4 < 16; ++i4) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(&sh.s_val[i4 * 4]);   // same address in every lane: a broadcast
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      run += q[e];
+      cum = (lane == i4 * 4 + e) ? rbf(run) : cum;
+    }
   }
 
   if (a.dbg_stop == 6) return;
