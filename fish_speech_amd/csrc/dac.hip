@@ -113,10 +113,13 @@ struct fmi_dac {
   size_t staging_bytes = 0;
   float* last_z = nullptr;
   int last_zC = 0, last_zL = 0;
-  // decode-side contraction arithmetic (ConvArgs::planes): 3 = bf16 matrix cores on 3-plane splits (fp32-class,
-  // default), 0 = fp32 matrix cores, 2 / 1 = fewer planes.  The encoder always runs on the fp32 matrix cores.
-  int decode_planes = 3;
+  // decode-side contraction arithmetic (ConvArgs::planes): 2 = fp16 matrix cores on the scaled two-term split
+  // (fp32-class, default), 0 = fp32 matrix cores, 1 = bf16 operands and results (autocast).  The encoder always runs
+  // on the fp32 matrix cores.
+  int decode_planes = 2;
   int cur_planes = 0;
+  bf16_t* pbuf[2] = {nullptr, nullptr};   // operand-plane hand-off buffers of the decoder
+  int64_t pbuf_bytes[2] = {0, 0};
   // one workspace per handle: request threads that share the codec object (inference_engine/__init__.py:179-192,
   // tools/api_server.py:115-122) are serialised here, whole call by whole call
   std::mutex mu;
@@ -373,11 +376,14 @@ int sync_out(fmi_dac* h, void* us) {
 // ---- layer runners (channel-major [B][C][L])
 
 int run_conv(fmi_dac* h, const Conv& c, const float* x, float* out, int B, int lin, int* lout_p, const float* snake,
-             const float* res, const float* gamma, int act) {
+             const float* res, const float* gamma, int act, const bf16_t* xp = nullptr, bf16_t* outp = nullptr,
+             const float* next_alpha = nullptr) {
   ConvArgs a{};
   a.w = c.w; a.x = x; a.out = out; a.snake_alpha = snake; a.res = res; a.gamma = gamma; a.B = B; a.lin = lin;
   a.act = act;
   a.planes = c.w.wb ? h->cur_planes : 0;
+  a.xp = xp; a.outp = outp; a.next_alpha = next_alpha;
+  FMI_REQUIRE((!xp && !outp) || a.planes > 0, "operand planes need the bf16-plane kernel");
   int lout;
   if (c.transposed) {  // CausalTransConvNet: (lin-1)*s + k - (k - s) = lin * s
     lout = lin * c.stride;
@@ -437,8 +443,58 @@ int run_convnext(fmi_dac* h, const ConvNeXt& c, float* x, int B, int C, int T) {
 
 // Decoder (modded_dac.py:760-801) on z = X [B][latent][len]; Y = scratch of the peak size
 // skip_cols: leading latent columns whose audio is not written (left context of an incremental decode)
+int64_t decode_peak_elems(const fmi_dac_config& c, int T);
+
+// The same with activations handed from conv to conv as bf16 operand planes (ConvArgs::xp / outp): Snake and the
+// three-way split run once, in the producer's epilogue.  X = z fp32 [B][latent][len]; X, Y double as the fp32
+// residual stream of the ResidualUnits (in place in one of them).
+int run_decoder_planes(fmi_dac* h, float* X, float* Y, int B, int len, float* audio_out_dev, int skip_cols) {
+  const fmi_dac_config& c = h->cfg;
+  const int64_t pbytes = (int64_t)B * decode_peak_elems(c, cdiv(len, 4)) * 2 * h->cur_planes;
+  for (int i = 0; i < 2; ++i)
+    if (h->pbuf_bytes[i] < pbytes) {
+      FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+      if (h->pbuf[i]) hipFree(h->pbuf[i]);
+      h->pbuf[i] = nullptr;
+      h->pbuf_bytes[i] = 0;
+      FMI_CHECK_HIP(hipMalloc((void**)&h->pbuf[i], (size_t)pbytes));
+      h->pbuf_bytes[i] = pbytes;
+    }
+  bf16_t *cur = h->pbuf[0], *oth = h->pbuf[1];   // every conv reads `cur` and writes `oth`, then they swap
+  int l2;
+  // first conv reads fp32 z; its output only feeds block 0's Snake + transposed conv
+  FMI_CHECK(run_conv(h, h->dec_in, X, nullptr, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE, nullptr, cur, h->dec[0].alpha));
+  for (size_t bi = 0; bi < h->dec.size(); ++bi) {
+    const DecBlock& db = h->dec[bi];
+    // transposed conv: fp32 out = residual stream of the three ResidualUnits, planes = snake_a1(out) for ru[0].c7
+    FMI_CHECK(run_conv(h, db.up, nullptr, X, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE, cur, oth, db.ru[0].a1));
+    std::swap(cur, oth);
+    len = l2;
+    for (int r = 0; r < 3; ++r) {
+      const ResUnit& ru = db.ru[r];
+      FMI_CHECK(run_conv(h, ru.c7, nullptr, nullptr, B, len, nullptr, nullptr, nullptr, nullptr, ACT_NONE, cur, oth, ru.a2));
+      std::swap(cur, oth);
+      const bool last_ru = r == 2, last_block = bi + 1 == h->dec.size();
+      // who reads this unit's output next: the next unit's first Snake, the next block's Snake, or the final conv (fp32)
+      const float* na = !last_ru ? db.ru[r + 1].a1 : (last_block ? nullptr : h->dec[bi + 1].alpha);
+      FMI_CHECK(run_conv(h, ru.c1, nullptr, X, B, len, nullptr, nullptr, X, nullptr, ACT_NONE, cur,
+                         (last_ru && last_block) ? nullptr : oth, na));
+      std::swap(cur, oth);
+    }
+  }
+  int hop = 1;
+  for (int i = 0; i < 4; ++i) hop *= c.decoder_rates[i];
+  (void)Y;
+  return launch_final_conv_tanh(X, h->dec_alpha, h->final_w, h->final_b, audio_out_dev, B, c.decoder_dim >> 4, len,
+                                skip_cols * hop, h->stream);
+}
+
 int run_decoder(fmi_dac* h, float* X, float* Y, int B, int len, float* audio_out_dev, int skip_cols = 0) {
   const fmi_dac_config& c = h->cfg;
+  static const bool fused_off = []() { const char* e = getenv("FMI_DAC_NO_PLANE_HANDOFF"); return e && atoi(e) != 0; }();
+  bool chain16 = (c.decoder_dim >> 4) % 16 == 0;   // every stage's channel count is a multiple of 16
+  if (h->cur_planes > 0 && chain16 && !fused_off && h->dec.size() == 4 && h->dec_in.w.wb)
+    return run_decoder_planes(h, X, Y, B, len, audio_out_dev, skip_cols);
   int l2;
   FMI_CHECK(run_conv(h, h->dec_in, X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
   std::swap(X, Y);
@@ -547,6 +603,8 @@ void fmi_dac_destroy(fmi_dac* h) {
   for (auto& b : h->buf)
     if (b.p) hipFree(b.p);
   if (h->staging) hipFree(h->staging);
+  for (auto p : h->pbuf)
+    if (p) hipFree(p);
   hipEventDestroy(h->ev_in);
   hipEventDestroy(h->ev_out);
   hipStreamDestroy(h->stream);
@@ -659,7 +717,7 @@ int fmi_dac_set_precision(fmi_dac* h, int planes) {
   std::unique_lock<std::mutex> lock_;
   if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h, "null handle");
-  FMI_REQUIRE(planes >= 0 && planes <= 3, "planes must be 0 (fp32 matrix cores) or 1..3 (bf16 planes)");
+  FMI_REQUIRE(planes >= 0 && planes <= 2, "precision must be 0 (fp32 matrix cores), 1 (bf16, autocast) or 2 (fp16 split)");
   h->decode_planes = planes;
   return FMI_OK;
 }

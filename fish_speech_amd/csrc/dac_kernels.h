@@ -16,9 +16,10 @@ struct ConvW {
   const float* bias = nullptr;  // [cout] or nullptr
   int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0;
   int phases = 1, taps = 1;
-  // the same weights as three bf16 planes hi/mid/lo with hi + mid + lo == w to 24 bits (launch_split_conv_planes):
-  //   wb[phase][tap][ci_pad16/16][plane][co_pad][16]   (16-byte halves of a [16] row swapped on rows with bit 3 set)
-  // operands of the bf16 matrix cores (conv_mfma_bf16_kernel); nullptr = this layer only has the fp32 path
+  // the same weights as 16-bit operand planes of the bf16 / fp16 matrix cores (launch_split_conv_planes):
+  //   wb[phase][tap][ci_pad16/16][slot][co_pad][16]   (16-byte halves of a [16] row swapped on rows with bit 3 set)
+  //   slot 0 = bf16(w); slots 1, 2 = the fp16 split f16(w), f16((w - hi) * 2048)
+  // nullptr = this layer only has the fp32 path
   const bf16_t* wb = nullptr;
   int cin_pad16 = 0;
 };
@@ -39,10 +40,18 @@ struct ConvArgs {
   int out_stride;       // output column step per computed column (1; stride for transposed)
   int act;
   // arithmetic of the contraction: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32, an fmaf chain);
-  // 3 = bf16 matrix cores on three-plane splits of both operands, 6 partial products, fp32 accumulation
-  //     (fp32-class: drops only terms below 2^-24 of a product); 2 = two planes, 3 products (~2^-16);
-  // 1 = one plane (operands rounded to bf16: what torch.autocast(bfloat16) makes of a conv / linear)
+  // 2 = fp16 matrix cores on a two-term split of both operands with a 2^11-scaled low part: three products, two fp32
+  //     accumulators (fp32-class: what is dropped is below 2^-22 of a product);
+  // 1 = bf16 matrix cores, operands and result rounded to bf16 (what torch.autocast(bfloat16) makes of a conv / linear)
   int planes;
+  // bf16-plane kernel only: activations handed from conv to conv as ready operand planes, so that Snake and the
+  // three-way split are computed ONCE by the producer's epilogue instead of by every consumer work-group's staging:
+  //   xp    input planes [B][cin/16][planes][lin][16] (replaces x / snake_alpha; cin % 16 == 0), or nullptr
+  //   outp  if set, the epilogue also writes planes of snake(out, next_alpha) ([B][cout/16][planes][lout][16]);
+  //         `out` may then be nullptr when nobody reads the fp32 tensor
+  const bf16_t* xp;
+  bf16_t* outp;
+  const float* next_alpha;
 };
 // out[b][co][q*out_stride + phase] = res + gamma * act(bias + sum_ci sum_tap w[phase][tap][ci][co] *
 //                                    snake(x)[b][ci][q*x_stride + tap_base + tap*tap_step])

@@ -299,6 +299,22 @@ __device__ inline void split3_pk(float x0, float x1, uint32_t& h, uint32_t& m, u
   l = cvt_pk_bf16_f32(r0, r1);
 }
 
+// fp16 two-term split with a scaled low part: x = hi + lo, hi = f16(x), lo16 = f16((x - hi) * 2048).  The products
+// hi*hi accumulate in one fp32 accumulator, hi*lo16 + lo16*hi in a second one that is folded in with weight 2^-11:
+// three v_mfma_f32_32x32x16_f16 per 16 reduction steps, and what is dropped (lo*lo, the f16 rounding of lo) is below
+// 2^-22 of a product -- fp32-class, at half the matrix work of the six-product bf16 scheme (f16 carries 11 significant
+// bits against bf16's 8).  Range: |x| < 65504; the scaling keeps lo16 out of the f16 subnormals.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_LO_SCALE = 2048.0f;
+__device__ inline void split2_f16_pk(float x0, float x1, uint32_t& h, uint32_t& l) {
+  const f16x2 hv = {(_Float16)x0, (_Float16)x1};
+  const float r0 = (x0 - (float)hv[0]) * F16_LO_SCALE, r1 = (x1 - (float)hv[1]) * F16_LO_SCALE;
+  const f16x2 lv = {(_Float16)r0, (_Float16)r1};
+  h = *reinterpret_cast<const uint32_t*>(&hv);
+  l = *reinterpret_cast<const uint32_t*>(&lv);
+}
+
 __host__ __device__ inline int64_t conv_wb_index(int tapg, int ci, int co, int plane, int cin_pad16, int cout_pad) {
   return (((((int64_t)tapg * (cin_pad16 >> 4) + (ci >> 4)) * 3 + plane) * cout_pad + co) << 4) +
          ((((ci >> 3) ^ (co >> 3)) & 1) << 3) + (ci & 7);
@@ -314,10 +330,11 @@ __global__ void split_conv_planes_kernel(const float* __restrict__ w, bf16_t* __
     const int ci = cp * 2;
     const float x0 = ci < cin_pad ? w[conv_w_index(tg, ci, co, cin_pad, cout_pad)] : 0.f;
     const float x1 = ci + 1 < cin_pad ? w[conv_w_index(tg, ci + 1, co, cin_pad, cout_pad)] : 0.f;
-    uint32_t h, m, l;
-    split3_pk(x0, x1, h, m, l);
-    *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 0, cin_pad16, cout_pad)) = h;
-    *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 1, cin_pad16, cout_pad)) = m;
+    // slot 0: bf16(w) (the autocast mode's operand); slots 1, 2: the fp16 split (hi, scaled lo)
+    uint32_t h, l;
+    split2_f16_pk(x0, x1, h, l);
+    *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 0, cin_pad16, cout_pad)) = cvt_pk_bf16_f32(x0, x1);
+    *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 1, cin_pad16, cout_pad)) = h;
     *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 2, cin_pad16, cout_pad)) = l;
   }
 }
@@ -331,13 +348,17 @@ int launch_split_conv_planes(const float* w_packed, bf16_t* wb, int tapgroups, i
   return FMI_OK;
 }
 
-template <int MT, int NT, int G, int NP, int TAPS>
-__global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
+// TAPS = 7: the tap loop is unrolled (operand reads of the next tap overlap the MFMAs of the current one).
+// TC > 0: the weight tile is brought in TC taps at a time (k = 7 as 4 + 3): a third of the LDS per work-group, so two
+// or three work-groups share a CU and one's staging phase hides behind another's matrix phase.
+template <int MT, int NT, int G, int NP, int TAPS, int TC>
+__global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
-  const int taps = TAPS > 0 ? TAPS : a.w.taps;            // TAPS = 7: the tap loop is unrolled (operand reads of the
-  char* Ws = reinterpret_cast<char*>(smem);                 // next tap overlap the MFMAs of the current one)
-  const int nw_bytes = taps * G * NP * CO_T * 32;
+  const int taps = TAPS > 0 ? TAPS : a.w.taps;
+  const int wt = TC > 0 ? TC : taps;                        // taps resident in Ws at a time
+  char* Ws = reinterpret_cast<char*>(smem);                 // [wt][G][NP][CO_T] rows of 32 bytes
+  const int nw_bytes = wt * G * NP * CO_T * 32;
   char* Xs = Ws + nw_bytes;                                 // [G][NP][wx] columns of 32 bytes
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -353,30 +374,53 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
   const bf16_t* wph = a.w.wb + ((((int64_t)phase * taps * cgs * 3) * a.w.cout_pad + co0) << 4);
   const bool do_snake = a.snake_alpha != nullptr;
 
-  f32x16 acc[MT][NT];
+  // NP = 1: bf16 operands (autocast), one product.  NP = 2: fp16 split, acc = hi*hi, acx = hi*lo16 + lo16*hi.
+  constexpr int SLOT0 = NP == 2 ? 1 : 0;       // first weight slot of this mode (see split_conv_planes_kernel)
+  f32x16 acc[MT][NT], acx[NP == 2 ? MT : 1][NP == 2 ? NT : 1];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if (NP == 2) acx[i][j][r] = 0.f;
+      }
 
   const int qw = wave * NT * 32;
-  const int n_rows = taps * G * NP;    // (tap, group, plane) rows of the weight tile, MT KiB each
   const int nblk = (wx + 63) >> 6;
   const char* a_lane = Ws + li * 32 + (((lk ^ (li >> 3)) & 1) << 4);
+  auto fetch_w = [&](int cg0, int t0, int nt) {   // (tap, group, plane) rows of taps [t0, t0 + nt), MT KiB each
+    for (int p = wave; p < nt * G * NP * MT; p += 4) {
+      const int row = p / MT, pc = p - row * MT;
+      const int pl = row % NP, tg = row / NP;
+      const int tp = t0 + tg / G, g = tg % G;
+      const char* gsrc = reinterpret_cast<const char*>(wph + (((((int64_t)tp * cgs + cg0 + g) * 3 + SLOT0 + pl) * a.w.cout_pad) << 4)) +
+                         pc * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)(Ws + p * 1024), 16, 0, 0);
+    }
+  };
 
   // (A register prefetch of the next step's input tile before the matrix phase was measured and is NOT used: 111.9 vs
   // 106.2 ms per batch-8 decode -- the waves wait on the barrier-separated phases, not on that load latency.)
   for (int cg0 = 0; cg0 < cgs; cg0 += G) {
-    for (int p = wave; p < n_rows * MT; p += 4) {
-      const int row = p / MT, pc = p - row * MT;
-      const int pl = row % NP, tg = row / NP;
-      const int tp = tg / G, g = tg - tp * G;
-      const char* gsrc = reinterpret_cast<const char*>(wph + (((((int64_t)tp * cgs + cg0 + g) * 3 + pl) * a.w.cout_pad) << 4)) +
-                         pc * 1024 + lane * 16;
-      __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)(Ws + p * 1024), 16, 0, 0);
-    }
+    fetch_w(cg0, 0, wt < taps ? wt : taps);
+    if (a.xp) {   // operand planes written by the producing conv: a plain copy (two lanes per 32-byte column)
+      const char* xpb = reinterpret_cast<const char*>(a.xp) + (int64_t)b * cgs * NP * a.lin * 32;
+      const int nb32 = (wx + 31) >> 5;
+      for (int it = wave; it < G * NP * nb32; it += 4) {
+        const int gp = it / nb32, cb = it - gp * nb32;
+        const int g = gp / NP, pl = gp - g * NP;
+        const int c = cb * 32 + (lane >> 1), h = lane & 1;
+        const int col = c0 + c;
+        if (c < wx) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (col >= 0 && col < a.lin)
+            v = *reinterpret_cast<const u32x4*>(xpb + (((int64_t)(cg0 + g) * NP + pl) * a.lin + col) * 32 + h * 16);
+          *reinterpret_cast<u32x4*>(Xs + ((int64_t)(g * NP + pl) * wx + c) * 32 + (((h ^ (c >> 3)) & 1) << 4)) = v;
+        }
+      }
+    } else
     // input tile: item = (group, 8-channel half, 64-column block); a lane owns one column, splits its 8 channels
     for (int it = wave; it < 2 * G * nblk; it += 4) {
       const int pair = it / nblk, cb = it - pair * nblk;
@@ -407,22 +451,31 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
               }
           }
         }
-        u32x4 ph, pm, pl;
+        u32x4 ph, pl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          uint32_t hh, mm, ll;
-          split3_pk(v[2 * e], v[2 * e + 1], hh, mm, ll);
-          ph[e] = hh; pm[e] = mm; pl[e] = ll;
+          if (NP == 2) {
+            uint32_t hh, ll;
+            split2_f16_pk(v[2 * e], v[2 * e + 1], hh, ll);
+            ph[e] = hh; pl[e] = ll;
+          } else {
+            ph[e] = cvt_pk_bf16_f32(v[2 * e], v[2 * e + 1]);
+          }
         }
         char* dst = Xs + ((int64_t)(g * NP) * wx + c) * 32 + (((h ^ (c >> 3)) & 1) << 4);
         *reinterpret_cast<u32x4*>(dst) = ph;
-        if (NP > 1) *reinterpret_cast<u32x4*>(dst + (int64_t)wx * 32) = pm;
-        if (NP > 2) *reinterpret_cast<u32x4*>(dst + (int64_t)2 * wx * 32) = pl;
+        if (NP == 2) *reinterpret_cast<u32x4*>(dst + (int64_t)wx * 32) = pl;
       }
     }
     __syncthreads();   // drains the LDS-DMA too (vmcnt(0) is part of the barrier's fence)
 #pragma unroll(TAPS > 0 ? TAPS : 1)
     for (int tp = 0; tp < taps; ++tp) {
+      const int tl = TC > 0 ? tp % TC : tp;      // tap's place in the resident part of the weight tile
+      if (TC > 0 && tp > 0 && tl == 0) {         // next part: everybody is done with the resident one
+        __syncthreads();
+        fetch_w(cg0, tp, taps - tp < TC ? taps - tp : TC);
+        __syncthreads();
+      }
       const int xoff = tap_off0 + tp * a.tap_step;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -431,28 +484,31 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
           for (int i = 0; i < MT; ++i)
-            af[pl][i] = *reinterpret_cast<const bf16x8*>(a_lane + (((tp * G + g) * NP + pl) * CO_T + i * 32) * 32);
+            af[pl][i] = *reinterpret_cast<const bf16x8*>(a_lane + (((tl * G + g) * NP + pl) * CO_T + i * 32) * 32);
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const int c = (qw + j * 32 + li) * a.x_stride + xoff;
             bf[pl][j] = *reinterpret_cast<const bf16x8*>(Xs + ((int64_t)(g * NP + pl) * wx + c) * 32 + (((lk ^ (c >> 3)) & 1) << 4));
           }
         }
-        // partial products, smallest first
-#define FMI_PROD(PA, PB)                                                                               \
-  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)         \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][i], bf[PB][j], acc[i][j], 0, 0, 0)
-        if constexpr (NP > 2) {
-          FMI_PROD(2, 0);
-          FMI_PROD(0, 2);
-          FMI_PROD(1, 1);
+        if constexpr (NP == 2) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const f16x8 a0 = *reinterpret_cast<const f16x8*>(&af[0][i]), a1 = *reinterpret_cast<const f16x8*>(&af[1][i]);
+              const f16x8 b0 = *reinterpret_cast<const f16x8*>(&bf[0][j]), b1 = *reinterpret_cast<const f16x8*>(&bf[1][j]);
+              acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acx[i][j], 0, 0, 0);
+              acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acx[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
         }
-        if constexpr (NP > 1) {
-          FMI_PROD(1, 0);
-          FMI_PROD(0, 1);
-        }
-        FMI_PROD(0, 0);
-#undef FMI_PROD
       }
     }
     __syncthreads();
@@ -468,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
     sg[tid] = a.gamma ? a.gamma[co] : 1.f;
   }
   __syncthreads();
-  float* ob = a.out + (int64_t)b * a.w.cout * a.lout;
+  float* ob = a.out ? a.out + (int64_t)b * a.w.cout * a.lout : nullptr;
   const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : ob;
   const bool has_res = a.res != nullptr;
 #pragma unroll
@@ -487,12 +543,13 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
       }
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
+        float o4[4];
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb + row0 + 8 * r4);
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg + row0 + 8 * r4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = r4 * 4 + e;
-          float v = acc[i][j][r] + b4[e];
+          float v = (NP == 2 ? acc[i][j][r] + acx[i][j][r] * (1.0f / F16_LO_SCALE) : acc[i][j][r]) + b4[e];
           if (NP == 1) v = rbf(v);   // autocast(bf16): the conv / linear returns bf16 (bias already bf16-rounded)
           if (a.act == ACT_GELU) {
             v = gelu_f(v);
@@ -500,34 +557,62 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(ConvArgs a, int nco
           }
           v = v * g4[e] + rv[r];     // LayerScale / ConvNeXt gamma (fp32 parameter) and the residual promote to fp32
           const int co = co0 + row0 + 8 * r4 + e;
-          if (live && co <= co_last) ob[co * a.lout + col] = v;
+          if (a.out && live && co <= co_last) ob[co * a.lout + col] = v;
+          o4[e] = v;
+        }
+        if (a.outp) {   // operand planes for the consumer: Snake of ITS alpha, three-way split, 4 channels = 8 bytes
+          const int co = co0 + row0 + 8 * r4;
+          if (live && co + 3 <= co_last) {
+            if (a.next_alpha) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o4[e] = snake_f(o4[e], a.next_alpha[co + e]);
+            }
+            uint32_t h0, l0 = 0, h1, l1 = 0;
+            if (NP == 2) {
+              split2_f16_pk(o4[0], o4[1], h0, l0);
+              split2_f16_pk(o4[2], o4[3], h1, l1);
+            } else {
+              h0 = cvt_pk_bf16_f32(o4[0], o4[1]);
+              h1 = cvt_pk_bf16_f32(o4[2], o4[3]);
+            }
+            char* dst = reinterpret_cast<char*>(a.outp) +
+                        ((((int64_t)b * (a.w.cout >> 4) + (co >> 4)) * NP) * a.lout + col) * 32 + (co & 15) * 2;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+            if (NP == 2) *reinterpret_cast<uint2*>(dst + (int64_t)a.lout * 32) = make_uint2(l0, l1);
+          }
         }
       }
     }
 }
 
-template <int MT, int NT, int G, int NP, int TAPS>
+template <int MT, int NT, int G, int NP, int TAPS, int TC>
 static int launch_conv_bf16_tt(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
   const ConvW& w = a.w;
   constexpr int TT = 4 * NT * 32, CO_T = MT * 32;
   const int wx = (TT - 1) * a.x_stride + span;
-  const size_t smem = (size_t)(G * NP * wx + w.taps * G * NP * CO_T) * 32;
+  const int wt = TC > 0 ? TC : w.taps;
+  const size_t smem = (size_t)(G * NP * wx + wt * G * NP * CO_T) * 32;
   FMI_REQUIRE(smem <= 160 * 1024, "conv(bf16): LDS tile of %zu bytes exceeds 160 KiB", smem);
   FMI_REQUIRE(w.cout_pad % CO_T == 0 && (w.cin_pad16 >> 4) % G == 0, "conv(bf16): tile does not divide the packed weight");
   dim3 grid(cdiv(ncols, TT), w.cout_pad / CO_T, a.B * w.phases), block(256);
   if (smem > 64 * 1024)
-    FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_bf16_kernel<MT, NT, G, NP, TAPS>,
+    FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_bf16_kernel<MT, NT, G, NP, TAPS, TC>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL((conv_mfma_bf16_kernel<MT, NT, G, NP, TAPS>), grid, block, smem, s, a, ncols, wx, tap_off0);
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<MT, NT, G, NP, TAPS, TC>), grid, block, smem, s, a, ncols, wx, tap_off0);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
 
 template <int MT, int NT, int G, int NP>
 static int launch_conv_bf16_t(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
-  static const bool unroll7 = []() { const char* e = getenv("FMI_CONV_UNROLL7"); return !e || atoi(e) != 0; }();
-  if (G == 1 && a.w.taps == 7 && unroll7) return launch_conv_bf16_tt<MT, NT, G, NP, 7>(a, ncols, tap_off0, span, s);
-  return launch_conv_bf16_tt<MT, NT, G, NP, 0>(a, ncols, tap_off0, span, s);
+  static const int tc_env = []() { const char* e = getenv("FMI_CONV_TC"); return e ? atoi(e) : -1; }();
+  if (G == 1 && a.w.taps == 7) {
+    const int tc = tc_env >= 0 ? tc_env : (NP >= 2 ? 4 : 0);   // one plane: the whole k = 7 tile is small enough
+    if (tc == 3) return launch_conv_bf16_tt<MT, NT, G, NP, 7, 3>(a, ncols, tap_off0, span, s);
+    if (tc > 0) return launch_conv_bf16_tt<MT, NT, G, NP, 7, 4>(a, ncols, tap_off0, span, s);
+    return launch_conv_bf16_tt<MT, NT, G, NP, 7, 0>(a, ncols, tap_off0, span, s);
+  }
+  return launch_conv_bf16_tt<MT, NT, G, NP, 0, 0>(a, ncols, tap_off0, span, s);
 }
 
 template <int NP>
@@ -536,18 +621,22 @@ static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span
   const int ct = w.cout_pad / 32;
   static const int env_mt = []() { const char* e = getenv("FMI_CONV_MT"); return e ? atoi(e) : 0; }();
   int MT = 1;
-  for (int m : {4, 3, 2})
+  for (int m : {3, 4, 2})   // 96-row tiles first: measured 95.6 vs 99.1 ms per batch-8 decode against 128-row-first
     if (ct % m == 0) { MT = m; break; }
   // the weight tile is NP planes of taps x 16 channels: 128 rows x 7 taps x 3 planes is 84 KiB -- one work-group per
   // CU; 64 rows keep two resident, which hides the staging phase of one behind the matrix phase of the other
-  const size_t wbytes = (size_t)w.taps * NP * MT * 32 * 32;
-  if (MT == 4 && wbytes > 48 * 1024) MT = 2;
+  const size_t wbytes = (size_t)(w.taps == 7 && NP >= 2 ? 4 : w.taps) * NP * MT * 32 * 32;   // resident part (TC = 4)
+  if (MT == 4 && wbytes > 50 * 1024) MT = 2;
   if (env_mt >= 1 && env_mt <= 4 && ct % env_mt == 0) MT = env_mt;
   const bool k1 = (w.taps == 1 && a.x_stride == 1 && (w.cin_pad16 >> 4) % 2 == 0);
 #define FMI_CONVB(MT_, NT_)                                                              \
   return k1 ? launch_conv_bf16_t<MT_, NT_, 2, NP>(a, ncols, tap_off0, span, s)           \
             : launch_conv_bf16_t<MT_, NT_, 1, NP>(a, ncols, tap_off0, span, s)
+  static const int env_nt = []() { const char* e = getenv("FMI_CONV_NT"); return e ? atoi(e) : 0; }();
   if (MT == 4) FMI_CONVB(4, 1);
+  // two accumulator sets (fp16 split): 96 x 256 tiles need 192 accumulator registers and spill; 96 x 128 fit
+  // (74.5 -> 67.8 ms per batch-8 decode)
+  if (MT == 3 && (env_nt == 1 || (NP == 2 && env_nt != 2))) FMI_CONVB(3, 1);
   if (MT == 3) FMI_CONVB(3, 2);
   if (MT == 2) FMI_CONVB(2, 2);
   FMI_CONVB(1, 4);
@@ -580,8 +669,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (a.planes > 0) {
     FMI_REQUIRE(w.wb && w.cin_pad16 % 16 == 0, "conv: this layer has no bf16 planes (planes=%d requested)", a.planes);
     if (a.planes == 1) return launch_conv_bf16<1>(a, ncols, tap_off0, span, s);
-    if (a.planes == 2) return launch_conv_bf16<2>(a, ncols, tap_off0, span, s);
-    return launch_conv_bf16<3>(a, ncols, tap_off0, span, s);
+    return launch_conv_bf16<2>(a, ncols, tap_off0, span, s);
   }
   const int ct = w.cout_pad / 32;
   // tile height: the largest of 4/3/2/1 (x32 rows) that divides the channel tiles, so that no

@@ -229,7 +229,7 @@ class MiDAC:
         self.frame_length = self.config.frame_length
         self.hop_length = int(math.prod(self.config.encoder_rates))
         self._dtype_probe = torch.empty(0, dtype=torch.float32, device=self.device)
-        self._planes = 3                       # decode-side arithmetic outside autocast (set_precision)
+        self._planes = 2                       # decode-side arithmetic outside autocast (set_precision)
         self._lock = threading.RLock()         # (precision, call) pairs of concurrent request threads stay together
 
     def __del__(self):
@@ -280,8 +280,9 @@ class MiDAC:
         check(self.lib.fmi_dac_weights_ready(self._h))
 
     def set_precision(self, planes: int):
-        """Decode-side contraction arithmetic: 3 = bf16 matrix cores on three-way operand splits (fp32-class, the
-        default), 0 = fp32 matrix cores (round-1 path), 2 / 1 = fewer bf16 planes (see include/fishmi.h)."""
+        """Decode-side contraction arithmetic: 2 = fp16 matrix cores on the scaled two-term operand split (fp32-class,
+        the default), 0 = fp32 matrix cores (round-1 path), 1 = bf16 operands and results (what autocast selects);
+        see include/fishmi.h."""
         with self._lock:
             check(self.lib.fmi_dac_set_precision(self._h, int(planes)))
             self._planes = int(planes)
@@ -293,7 +294,7 @@ class MiDAC:
         (fish_speech/inference_engine/__init__.py:179-192) -- every conv / linear rounds its operands and its result to
         bf16 with fp32 accumulation, as autocast does to F.conv1d / F.conv_transpose1d / F.linear; elementwise ops,
         norms and residual adds stay fp32 (torch's type promotion gives fp32 there too, parameters being fp32).
-        Outside autocast the configured precision applies (default: fp32-class three-plane arithmetic)."""
+        Outside autocast the configured precision applies (default: the fp32-class fp16-split arithmetic)."""
         planes = self._planes
         if torch.is_autocast_enabled("cuda"):
             if torch.get_autocast_dtype("cuda") != torch.bfloat16:

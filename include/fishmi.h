@@ -234,11 +234,12 @@ int fmi_dac_finalize_weights(fmi_dac* h, void* stream);
 int fmi_dac_weights_ready(fmi_dac* h);
 /* Arithmetic of the decode-side contractions (from_indices / decode / decode_tail; the encoder always uses the fp32
  * matrix cores so that its codes stay bit-comparable):
- *   3 (default) bf16 matrix cores on exact three-way bf16 splits of both operands, six partial products with fp32
- *               accumulation -- fp32-class results (the dropped terms are below 2^-24 of a product): the codec CLI's
+ *   2 (default) fp16 matrix cores on a two-term split of both operands, low part scaled by 2^11: three products, two
+ *               fp32 accumulators -- fp32-class results (what is dropped is below 2^-22 of a product): the codec CLI's
  *               fp32 mode, fish_speech/models/dac/inference.py:52-112;
  *   0           fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain), the round-1 path;
- *   2, 1        fewer planes (2: ~2^-16; 1: operands rounded to bf16 once). */
+ *   1           bf16 matrix cores, operands and result of every conv / linear rounded to bf16: what the engine's
+ *               torch.autocast(bfloat16) computes (fish_speech/inference_engine/__init__.py:179-192). */
 int fmi_dac_set_precision(fmi_dac* h, int planes);
 
 /* DAC.from_indices (fish_speech/models/dac/modded_dac.py:925-927): indices int64

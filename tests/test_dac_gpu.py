@@ -223,26 +223,26 @@ def test_codec_checkpoint_wrapping_and_engine_call_sites(small):
     assert np.array_equal(prompt_tokens.cpu().numpy(), z["codes"][0])
 
 
-def test_bf16_plane_arithmetic_vs_fp32_matrix_cores_and_oracle(full):
-    """The decode-side contractions run on the bf16 matrix cores over exact three-way bf16 splits of both operands
-    (six partial products, fp32 accumulation).  Against the fp32-matrix-core path of round 1 and the CPU oracle
-    (yaml-sized codec, 2 x 5 frames): three planes are fp32-class (waveform RMS error <= 1e-6 against the fp32 path,
-    <= 1e-4 against the oracle -- the parity bar); two planes ~2^-16 per product; one plane = operands rounded to
-    bf16, far outside the fp32 bar by construction (reported, bounded loosely)."""
+def test_fp16_split_arithmetic_vs_fp32_matrix_cores_and_oracle(full):
+    """The decode-side contractions run on the fp16 matrix cores over a two-term split of both operands whose low part
+    is scaled by 2^11 (three products, two fp32 accumulators; dropped terms < 2^-22 of a product).  Against the
+    fp32-matrix-core path of round 1 and the CPU oracle (yaml-sized codec, 2 x 5 frames): fp32-class -- waveform RMS
+    error <= 1e-6 against the fp32 path, <= 1e-4 against the oracle (the parity bar, met with two orders of
+    magnitude to spare); precision 1 (bf16 operands and results, the autocast mode) is far outside the fp32 bar by
+    construction and is bounded loosely here (its own test calibrates it against the oracle in the same mode)."""
     cfg, state, codec = full
     codes = D.make_codes(cfg, 2, 5, seed=8)
     want = D.DacOracle(cfg, state).from_indices(codes.clone())
     out = {}
-    for planes in (0, 3, 2, 1):
+    for planes in (0, 2, 1):
         codec.set_precision(planes)
         out[planes] = codec.from_indices(codes.clone().to(DEV)).cpu()
-    codec.set_precision(3)
+    codec.set_precision(2)
     sig = float(want.pow(2).mean().sqrt())
     e = {p: (rms(out[p], want), rms(out[p], out[0])) for p in out}
     print("codec precision sweep (rms vs oracle, vs fp32 matrix cores); signal rms", sig, e)
-    assert e[0][0] <= 1e-4 and e[3][0] <= 1e-4
-    assert e[3][1] <= 1e-6
-    assert e[2][1] <= 1e-4
+    assert e[0][0] <= 1e-4 and e[2][0] <= 1e-4
+    assert e[2][1] <= 1e-6
     assert e[1][1] <= 5e-2 * max(sig, 1e-3) + 1e-3
 
 

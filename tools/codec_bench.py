@@ -15,7 +15,7 @@ codes = torch.randint(0, 1024, (B, 10, T), generator=g, device=dev, dtype=torch.
 codec.from_indices(codes.clone()); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 flop = 2 * 727.15e9 * B * T / 215
-for planes in [int(v) for v in os.environ.get("PLANES", "3,0,2,1").split(",")]:
+for planes in [int(v) for v in os.environ.get("PLANES", "2,0,1").split(",")]:
     codec.set_precision(planes)
     codec.from_indices(codes.clone()); torch.cuda.synchronize()
     ts = []
