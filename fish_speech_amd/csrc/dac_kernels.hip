@@ -880,8 +880,91 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
   }
 }
 
+// The same attention with the K / V window of QT consecutive queries staged once in LDS (head_dim 64, window <= 128:
+// the quantizer's pre/post transformers).  Work-group = (16 queries, head, batch item), a wave takes 4 of the queries:
+//   scores   lane <-> key (two keys per lane), q broadcast from LDS, K columns read conflict-free (odd row stride);
+//   softmax  as in window_attn_kernel (same lane <-> key assignment, same reduction trees: identical p and den);
+//   output   lane <-> head dimension: o[d] = sum_j p[j] * V[d][j] in key order -- no cross-lane reduction at all
+//            (the old kernel paid 64 wave-wide reductions per query: 0.91 ms per layer at 8 x 215 frames).
+// A query's result depends only on its own position, so it is invariant under batch, total length and tiling.
+template <int QT>
+__global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                              int C, int L, int window) {
+  constexpr int HD = 64;
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  const int KT = QT + window - 1, RS = KT | 1;
+  float* Ks = wsm;
+  float* Vs = Ks + HD * RS;
+  float* Qs = Vs + HD * RS;          // [QT][HD]
+  float* Ps = Qs + QT * HD;          // [4][128]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int t0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
+  const float* qb = qkv + ((int64_t)b * 3 * C + h * HD) * L;
+  const float* kb = qb + (int64_t)C * L;
+  const float* vb = kb + (int64_t)C * L;
+  const int k0 = max(0, t0 - window + 1);
+  const int nk = min(L, t0 + QT) - k0;
+  for (int d = wave; d < HD; d += 4)
+    for (int c = lane; c < nk; c += 64) {
+      Ks[d * RS + c] = kb[(int64_t)d * L + k0 + c];
+      Vs[d * RS + c] = vb[(int64_t)d * L + k0 + c];
+    }
+  for (int i = tid; i < QT * HD; i += 256) {
+    const int d = i / QT, q = i % QT;
+    Qs[q * HD + d] = t0 + q < L ? qb[(int64_t)d * L + t0 + q] : 0.f;
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)HD);
+  float* pw = Ps + wave * 128;
+  for (int qi = wave; qi < QT; qi += 4) {
+    const int t = t0 + qi;
+    if (t >= L) break;
+    const int lo = max(0, t - window + 1);
+    const float* qrow = Qs + qi * HD;
+    float sc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lo + u * 64 + lane;
+      float a = 0.f;
+      if (j <= t) {
+        const float* kc = Ks + (j - k0);
+#pragma unroll 8
+        for (int d = 0; d < HD; ++d) a += qrow[d] * kc[d * RS];
+      }
+      sc[u] = j <= t ? a * scale : -INFINITY;
+    }
+    const float mx = wave_max(fmaxf(sc[0], sc[1]));
+    const float p0 = sc[0] > -INFINITY ? expf(sc[0] - mx) : 0.f, p1 = sc[1] > -INFINITY ? expf(sc[1] - mx) : 0.f;
+    const float den = wave_sum(p0 + p1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();               // the previous query's reads of pw are done
+    pw[lane] = p0;
+    pw[64 + lane] = p1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int n = t - lo + 1;
+    const float* vr = Vs + lane * RS + (lo - k0);  // lane = head dimension
+    float o = 0.f;
+    for (int jj = 0; jj < n; ++jj) o += pw[jj] * vr[jj];
+    out[((int64_t)b * C + h * HD + lane) * L + t] = o / den;
+  }
+}
+
 int launch_window_attn(const float* qkv, float* out, int B, int C, int L, int hd, int window, hipStream_t s) {
   FMI_REQUIRE(hd <= 64 && C % hd == 0, "window_attn: head_dim %d unsupported", hd);
+  constexpr int QT = 16;
+  const size_t smem = (size_t)(2 * 64 * ((QT + window - 1) | 1) + QT * 64 + 4 * 128) * sizeof(float);
+  static const bool lds_off = []() { const char* e = getenv("FMI_WATTN_OLD"); return e && atoi(e) != 0; }();
+  if (hd == 64 && window <= 128 && smem <= 80 * 1024 && !lds_off) {
+    if (smem > 64 * 1024)
+      FMI_CHECK_HIP(hipFuncSetAttribute((const void*)window_attn_lds_kernel<QT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)smem));
+    hipLaunchKernelGGL((window_attn_lds_kernel<QT>), dim3(cdiv(L, QT), C / hd, B), dim3(256), smem, s, qkv, out, C, L,
+                       window);
+    FMI_CHECK_HIP(hipGetLastError());
+    return FMI_OK;
+  }
   hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(L, 4), C / hd, B), dim3(256), 0, s, qkv, out, C, L, hd, window);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
