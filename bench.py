@@ -27,9 +27,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 # HBM bytes fetched per decode frame at batch 8, from the separate rocprofv3 --pmc FETCH_SIZE pass
-# (profiles/r01_pmc_fetch_decode.txt; KiB x 1024 x 2 = the gfx950 correction of MI355X_MICROARCH.md).
+# (profiles/r02_pmc_fetch_decode.txt; KiB x 1024 x 2 = the gfx950 correction of MI355X_MICROARCH.md).
 # PMC counters cannot be collected inside a timed run, so the figure is carried here with its provenance.
-PMC_FETCH_BYTES_PER_FRAME = 15.94e9
+PMC_FETCH_BYTES_PER_FRAME = 15.64e9
 
 FRAME_LEN = 2048          # samples per frame (modded_dac.py:833,861)
 SAMPLE_RATE = 44100
@@ -98,6 +98,9 @@ def algorithmic_bytes_per_frame(cfg, batch, mean_ctx):
     per_layer = qkv * d + d * cfg.n_head * cfg.head_dim + 3 * ffn * d
     slow = cfg.n_layer * per_layer
     fast = cfg.num_codebooks * cfg.n_fast_layer * per_layer
+    # fast layer 0 sees fast_embeddings[code] at codebook positions 1..ncb-1: its wqkv output is a pure function of the
+    # code and is read from a per-code table (one row per utterance) instead of streaming the matrix
+    fast -= (cfg.num_codebooks - 1) * qkv * d
     n_live = cfg.semantic_end_id - cfg.semantic_begin_id + 2
     heads = n_live * d + (cfg.num_codebooks - 1) * cfg.codebook_size * d
     kv = batch * cfg.n_layer * 2 * cfg.n_local_heads * cfg.head_dim * mean_ctx
@@ -465,7 +468,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 4),
                      "traffic": PMC_FETCH_BYTES_PER_FRAME if (N_FRAMES == 215 and BATCH == 8) else None,
-                     "kernel": "decode frame: 311 linear_skinny_kernel launches (weight streaming) + 36 attention, 40 fast-attention, "
+                     "kernel": "decode frame: 302 linear_skinny_kernel launches (weight streaming) + 36 attention, 40 fast-attention, "
                                "10 sampler launches, replayed as one hipGraph",
                      "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},
     }

@@ -10,8 +10,22 @@ import sys
 
 def main(path, n_frames):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != "FETCH_SIZE" or "fmi::" not in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == "FETCH_SIZE"]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    # load-time work is not part of a frame: runs of >= 256 back-to-back launches of one kernel (the 512 GEMV
+    # launches that tabulate fast layer 0's q|k|v per code, the weight packing) are dropped
+    keep, i = [], 0
+    while i < len(rows):
+        j = i
+        while j < len(rows) and rows[j]["Kernel_Name"] == rows[i]["Kernel_Name"] and rows[j]["Grid_Size"] == rows[i]["Grid_Size"]:
+            j += 1
+        if j - i < 256:
+            keep.extend(rows[i:j])
+        else:
+            print(f"# dropped a run of {j - i} consecutive launches of {rows[i]['Kernel_Name'].split('(')[0]} (load-time)")
+        i = j
+    for r in keep:
+        if "fmi::" not in r["Kernel_Name"]:
             continue
         k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
         agg[k][0] += 1
@@ -28,7 +42,7 @@ def main(path, n_frames):
     # the prefill frame runs the same tail (fast chain + heads) once; slow layers there use the tiled path
     print(f"\nHBM bytes fetched by the decode-frame kernels: {frame_bytes / 1e9:.3f} GB over the run "
           f"= {frame_bytes / (n_decode + 0.52) / 1e9:.3f} GB per decode frame "
-          f"(prefill-frame tail counted as 0.52 frame: 8.07+0.19 of 15.55 GB)")
+          f"(prefill-frame tail counted as 0.52 frame: the fast chain and the heads of a frame)")
 
 
 if __name__ == "__main__":
