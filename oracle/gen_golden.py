@@ -154,6 +154,8 @@ PEAKY_CASES = {
     "tiny_peaky_eos": ({}, dict(seed=8, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5, eos_code=17), (24, 8, 2), 96,
                        (0.7, 0.7, 1), 1234),
     "mid_peaky": (_MID, dict(seed=93, emb_gain=2.5, slow_gain=3.0, fast_gain=2.5), (40, 12, 3), 48, (0.7, 0.7, 1), 1234),
+    # the same model quantised by the reference's own WeightOnlyInt8QuantHandler (name suffix _int8)
+    "tiny_peaky_int8": ({}, dict(seed=1, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5), (24, 8, 1), 48, (0.7, 0.7, 1), 1234),
     "tiny_sampled": ({}, dict(seed=3, emb_gain=6.0, slow_gain=2.0, fast_gain=8.0, hot=(1.0, 0.95, 0.93), hot_every=3),
                      (24, 8, 3), 40, (0.7, 0.9, 30), 67),
 }
@@ -170,11 +172,12 @@ def gen_dualar_peaky():
         state = O.make_peaky_state(cfg, **skw)
         prompt = O.make_prompt(cfg, T, seed=pseed, n_semantic=nsem)
         tr = {}
+        int8 = name.endswith("_int8")
         tokens = _ref_generate(cfg, state, prompt, max_new, top_k, O.FmiUniform(seed=useed, stream=0), trace=tr,
-                               temperature=temp, top_p=top_p)
+                               temperature=temp, top_p=top_p, int8=int8)
         n = tokens.shape[1] - T
         # the oracle must reproduce the reference run bit for bit on this machine
-        orc = O.DualAROracle(cfg, state)
+        orc = O.DualAROracle(cfg, O.quantize_state_int8(cfg, state) if int8 else state)
         mine = O.generate(orc, prompt, max_new, temp, top_p, top_k, uniform_fn=O.FmiUniform(useed, 0))
         assert torch.equal(mine, tokens), name
         ids = live_ids(cfg)

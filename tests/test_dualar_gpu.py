@@ -735,6 +735,27 @@ def test_int8_gemv_equals_the_dequantised_bf16_gemv_and_the_reference_arithmetic
         assert torch.equal(one[0], a[0])
 
 
+def test_int8_generate_full_sequence_equals_the_reference_int8_run():
+    """Strict index parity of the weight-only-int8 path: the well-conditioned tiny model quantised by the REFERENCE's
+    WeightOnlyInt8QuantHandler, its generate() run (48 frames, every decision >= 8 bf16 steps of margin) against the HIP
+    path loaded from the same int8 checkpoint -- the whole sequence must be equal, and every teacher-forced decision."""
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR, generate
+    from tests.helpers import check_teacher_forced
+
+    cfg, state, z = load_dualar_case("tiny_peaky_int8")
+    q = O.quantize_state_int8(cfg, state)
+    mcfg = DualARConfig.from_any(cfg)
+    mcfg.weight_int8 = True
+    model = MiDualAR(mcfg, device=DEV, im_end_id=cfg.im_end_id).load_state_dict(q)
+    model.setup_caches(2, cfg.max_seq_len)
+    got = generate(model=model, prompt=torch.from_numpy(z["prompt"]), max_new_tokens=int(z["max_new"]), temperature=0.7,
+                   top_p=0.7, top_k=1, seed=int(z["uniform_seed"])).numpy()
+    assert got.shape == z["tokens"].shape and np.array_equal(got, z["tokens"])
+    st = check_teacher_forced(hip_step_fn(model, cfg, int(z["uniform_seed"])), cfg, z)
+    n = z["tokens"].shape[1] - z["prompt"].shape[1]
+    assert st["frames"] == n and st["exact"] == st["decisions"] == n * cfg.num_codebooks, st
+
+
 def test_int8_model_vs_the_reference_int8_fixture():
     """The tiny model quantised by the reference's WeightOnlyInt8QuantHandler (fixture dualar_tiny_int8.npz): the
     HIP path loaded from the int8 checkpoint (int8 tiles for decode, dequantised tiles for prefill, scales in the

@@ -43,7 +43,7 @@ def test_oracle_free_running_vs_reference_golden(case, mode, top_k):
     assert np.array_equal(y[:, : T + k], want[:, : T + k])
 
 
-@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled"])
+@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled", "tiny_peaky_int8"])
 def test_well_conditioned_fixtures_full_sequence_and_margins(case):
     """The well-conditioned fixtures (oracle.make_peaky_state; written by the unmodified reference's generate()):
     every decision of the reference run has >= 8 bf16 steps of margin (greedy) -- re-derived here from the stored
@@ -52,6 +52,8 @@ def test_well_conditioned_fixtures_full_sequence_and_margins(case):
     from tests.helpers import bf16_from_u16, check_teacher_forced, oracle_step_fn
 
     cfg, state, z = load_dualar_case(case)
+    if case.endswith("_int8"):     # the reference ran its WeightOnlyInt8QuantHandler over this state
+        state = O.quantize_state_int8(cfg, state)
     want = z["tokens"]
     T = z["prompt"].shape[1]
     n = want.shape[1] - T
