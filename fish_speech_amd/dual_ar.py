@@ -425,6 +425,10 @@ class MiDualAR:
         if old is None:
             return 0
         new = prompt.detach().to("cpu", torch.int64)
+        # prompts of up to 16 rows run through the decode GEMV, longer ones through the tiled GEMM: K/V written by one
+        # are not bit-identical to what the other would write, so a prefix is only reused within the same class
+        if (old.shape[1] > 16) != (new.shape[1] > 16):
+            return 0
         m = min(old.shape[1], new.shape[1] - 1)
         if m <= 0:
             return 0

@@ -968,3 +968,27 @@ def test_mfma_flash_attention_ragged_batch_equals_single_prompts():
         l1, _, h1, _ = model.debug_taps(1)
         model.release(0)
         assert torch.equal(l1[0], logits[i]) and torch.equal(h1[0], hidden[i]), i
+
+
+def test_prefix_reuse_is_bit_identical_for_every_length_class():
+    """MiDualAR.prefill(reuse_prefix=True) against plain prefills, slot kept between calls: a long prompt extended
+    (suffix of 3 rows: forced through the tiled GEMM), a short prompt (<= 16 rows: decode GEMV) extended to a long one
+    (no reuse: the kernels differ), a short one extended within 16 rows, an unrelated prompt (no common prefix), and
+    the same prompt again (all but the last column reused).  Every generation equals the one without reuse."""
+    from fish_speech_amd.dual_ar import generate
+
+    cfg, state, _ = load_dualar_case("mid_peaky")
+    model = _make_model(cfg, state, max_batch=1)
+    base = O.make_prompt(cfg, 70, seed=3, n_semantic=20)
+    other = O.make_prompt(cfg, 33, seed=4, n_semantic=5)
+    seq = [base[:, :40], base[:, :43], base[:, :70], other, base[:, :9], base[:, :14], base[:, :30], base[:, :30]]
+    kw = dict(max_new_tokens=6, temperature=0.7, top_p=0.7, top_k=1, seed=11)
+    want = [generate(model=model, prompt=p, **kw) for p in seq]
+    model.prefilled_rows = model.reused_rows = 0
+    got = [generate(model=model, prompt=p, reuse_prefix=True, **kw) for p in seq]
+    model.release(0)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+    # 40 | +3 (40 reused) | +27 (43 reused) | 33 new | 9 new | +5 (9 reused, both short) | 30 new (short -> long) | 29 reused
+    assert model.reused_rows == 40 + 43 + 9 + 29, model.reused_rows
+    assert model.prefilled_rows == sum(p.shape[1] for p in seq) - model.reused_rows
