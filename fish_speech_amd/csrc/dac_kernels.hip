@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
 
   const int qw = wave * NT * 32;
   const int nblk = (wx + 63) >> 6;
+  constexpr int SU = G >= 4 ? 4 : 2;
   const char* a_lane = Ws + li * 32 + (((lk ^ (li >> 3)) & 1) << 4);
   auto fetch_w = [&](int cg0, int t0, int nt) {   // (tap, group, plane) rows of taps [t0, t0 + nt), MT KiB each
     for (int p = wave; p < nt * G * NP * MT; p += 4) {
@@ -421,50 +422,63 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
         }
       }
     } else
-    // input tile: item = (group, 8-channel half, 64-column block); a lane owns one column, splits its 8 channels
-    for (int it = wave; it < 2 * G * nblk; it += 4) {
-      const int pair = it / nblk, cb = it - pair * nblk;
-      const int g = pair >> 1, h = pair & 1;
-      const int c = cb * 64 + lane;
-      const int ci = (cg0 + g) * 16 + h * 8;   // wave-uniform
-      const int col = c0 + c;
-      const int nval = a.w.cin - ci;           // real channels among the 8 (padding reads as zero)
-      float v[8];
+    // input tile: item = (group, 8-channel half, 64-column block); a lane owns one column, splits its 8 channels.
+    // SU items per wave are in flight together (all their loads issue before the first conversion): a k = 1 layer
+    // of the codec transformer is a chain of load round trips, one per item, when they go one at a time.
+    for (int it0 = wave; it0 < 2 * G * nblk; it0 += 4 * SU) {
+      float v[SU][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
-      if (c < wx) {
-        if (col >= 0 && col < a.lin && nval > 0) {
+      for (int u = 0; u < SU; ++u) {
+        const int it = it0 + 4 * u;
+        const int pair = it / nblk, cb = it - pair * nblk;
+        const int c = cb * 64 + lane;
+        const int ci = (cg0 + (pair >> 1)) * 16 + (pair & 1) * 8;   // wave-uniform
+        const int col = c0 + c;
+        const int nval = a.w.cin - ci;           // real channels among the 8 (padding reads as zero)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+        if (it < 2 * G * nblk && c < wx && col >= 0 && col < a.lin && nval > 0) {
           const float* xp = xb + (int64_t)ci * a.lin + col;
           if (nval >= 8) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = xp[(int64_t)e * a.lin];
-            if (do_snake) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = snake_f(v[e], a.snake_alpha[ci + e]);
-            }
+            for (int e = 0; e < 8; ++e) v[u][e] = xp[(int64_t)e * a.lin];
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-              if (e < nval) {
-                const float t = xp[(int64_t)e * a.lin];
-                v[e] = do_snake ? snake_f(t, a.snake_alpha[ci + e]) : t;
-              }
+              if (e < nval) v[u][e] = xp[(int64_t)e * a.lin];
           }
         }
-        u32x4 ph, pl;
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (NP == 2) {
-            uint32_t hh, ll;
-            split2_f16_pk(v[2 * e], v[2 * e + 1], hh, ll);
-            ph[e] = hh; pl[e] = ll;
-          } else {
-            ph[e] = cvt_pk_bf16_f32(v[2 * e], v[2 * e + 1]);
+      for (int u = 0; u < SU; ++u) {
+        const int it = it0 + 4 * u;
+        const int pair = it / nblk, cb = it - pair * nblk;
+        const int g = pair >> 1, h = pair & 1;
+        const int c = cb * 64 + lane;
+        const int ci = (cg0 + g) * 16 + h * 8;
+        const int col = c0 + c;
+        const int nval = a.w.cin - ci;
+        if (it < 2 * G * nblk && c < wx) {
+          if (do_snake && col >= 0 && col < a.lin) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e < nval) v[u][e] = snake_f(v[u][e], a.snake_alpha[ci + e]);
           }
+          u32x4 ph, pl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (NP == 2) {
+              uint32_t hh, ll;
+              split2_f16_pk(v[u][2 * e], v[u][2 * e + 1], hh, ll);
+              ph[e] = hh; pl[e] = ll;
+            } else {
+              ph[e] = cvt_pk_bf16_f32(v[u][2 * e], v[u][2 * e + 1]);
+            }
+          }
+          char* dst = Xs + ((int64_t)(g * NP) * wx + c) * 32 + (((h ^ (c >> 3)) & 1) << 4);
+          *reinterpret_cast<u32x4*>(dst) = ph;
+          if (NP == 2) *reinterpret_cast<u32x4*>(dst + (int64_t)wx * 32) = pl;
         }
-        char* dst = Xs + ((int64_t)(g * NP) * wx + c) * 32 + (((h ^ (c >> 3)) & 1) << 4);
-        *reinterpret_cast<u32x4*>(dst) = ph;
-        if (NP == 2) *reinterpret_cast<u32x4*>(dst + (int64_t)wx * 32) = pl;
       }
     }
     __syncthreads();   // drains the LDS-DMA too (vmcnt(0) is part of the barrier's fence)
@@ -629,10 +643,36 @@ static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span
   if (MT == 4 && wbytes > 50 * 1024) MT = 2;
   if (env_mt >= 1 && env_mt <= 4 && ct % env_mt == 0) MT = env_mt;
   const bool k1 = (w.taps == 1 && a.x_stride == 1 && (w.cin_pad16 >> 4) % 2 == 0);
-#define FMI_CONVB(MT_, NT_)                                                              \
-  return k1 ? launch_conv_bf16_t<MT_, NT_, 2, NP>(a, ncols, tap_off0, span, s)           \
-            : launch_conv_bf16_t<MT_, NT_, 1, NP>(a, ncols, tap_off0, span, s)
+  // k = 1 layers stage G x 16 channels per step.  A small grid (the codec transformer and the chunks of a streaming
+  // decode: one or two column tiles per utterance) is a serial chain of steps per work-group with most CUs idle: it
+  // takes 32-row tiles (4x the work-groups) and 64-channel steps.  Neither changes the accumulation order of an
+  // output element, so results do not depend on the choice (incremental decodes stay bit-identical to offline).
   static const int env_nt = []() { const char* e = getenv("FMI_CONV_NT"); return e ? atoi(e) : 0; }();
+  static const int env_g = []() { const char* e = getenv("FMI_CONV_K1G"); return e ? atoi(e) : 0; }();
+  static const int env_small = []() { const char* e = getenv("FMI_CONV_K1SMALL"); return e ? atoi(e) : 1; }();
+  int kg = 2;
+  bool small = false;
+  if (k1) {
+    const int cgs = w.cin_pad16 >> 4;
+    const int64_t col_tiles = (int64_t)cdiv(ncols, 128) * a.B;
+    small = env_small && col_tiles * (ct / MT) < 256 && env_mt == 0;
+    if (small)
+      for (int m : {4, 3, 2, 1})
+        if (ct % m == 0 && (col_tiles * (ct / m) >= 256 || m == 1)) { MT = m; break; }
+    const int want = env_g ? env_g : (small ? 4 : 2);
+    const int nt = small || MT == 4 ? 1 : MT == 3 ? ((env_nt == 1 || (NP == 2 && env_nt != 2)) ? 1 : 2) : MT == 2 ? 2 : 4;
+    for (int g : {8, 4, 2})   // both tiles of a step within 128 KiB of LDS
+      if (g <= want && cgs % g == 0 && (size_t)g * NP * (4 * nt * 32 + MT * 32) * 32 <= 128 * 1024) { kg = g; break; }
+  }
+#define FMI_CONVB(MT_, NT_)                                                              \
+  do {                                                                                   \
+    if (!k1) return launch_conv_bf16_t<MT_, NT_, 1, NP>(a, ncols, tap_off0, span, s);    \
+    if (kg == 8) return launch_conv_bf16_t<MT_, NT_, 8, NP>(a, ncols, tap_off0, span, s); \
+    if (kg == 4) return launch_conv_bf16_t<MT_, NT_, 4, NP>(a, ncols, tap_off0, span, s); \
+    return launch_conv_bf16_t<MT_, NT_, 2, NP>(a, ncols, tap_off0, span, s);             \
+  } while (0)
+  if (small && MT == 2) FMI_CONVB(2, 1);
+  if (small && MT == 1) FMI_CONVB(1, 1);
   if (MT == 4) FMI_CONVB(4, 1);
   // two accumulator sets (fp16 split): 96 x 256 tiles need 192 accumulator registers and spill; 96 x 128 fit
   // (74.5 -> 67.8 ms per batch-8 decode)

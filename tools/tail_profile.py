@@ -1,0 +1,17 @@
+"""One incremental codec decode (frames [T0, T1) of 8 utterances) repeated: run under rocprofv3 --kernel-trace."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import synthetic_codec_state
+from fish_speech_amd.dac import DacConfig, MiDAC
+
+dev = torch.device("cuda:0")
+cfg = DacConfig()
+codec = MiDAC(cfg, device=dev)
+codec.load_folded_state(synthetic_codec_state(cfg, dev))
+B, T0, T1 = 8, int(os.environ.get("T0", 40)), int(os.environ.get("T1", 72))
+g = torch.Generator(device=dev).manual_seed(0)
+codes = torch.randint(0, 1024, (B, 10, T1), generator=g, device=dev, dtype=torch.int64)
+for _ in range(int(os.environ.get("N", 5))):
+    codec.from_indices_tail(codes.clone(), T0)
+torch.cuda.synchronize()
