@@ -124,6 +124,15 @@ struct fmi_dac {
   // tools/api_server.py:115-122) are serialised here, whole call by whole call
   std::mutex mu;
   std::vector<ConvW> plane_jobs;
+  // quantizer-side state of an incremental (streaming) decode: fmi_dac_decode_tail_cached
+  struct {
+    int B = 0, T = 0, cap = 0;            // utterances, frames covered so far, frame capacity of the buffers
+    int64_t id = 0;                       // the caller's stream id the state belongs to
+    int planes = -1;                      // arithmetic (fmi_dac_set_precision) the state was computed with
+    std::vector<float*> qkv;              // per post-transformer layer: roped q|k|v of every frame [B][3C][cap]
+    float* tf_out = nullptr;              // transformer output [B][C][cap]
+    float* z = nullptr;                   // upsampled latents [B][latent][4 cap]
+  } st;
 };
 
 namespace {
@@ -562,6 +571,88 @@ int run_quantizer_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float**
   return FMI_OK;
 }
 
+void free_stream_state(fmi_dac* h) {
+  for (float* p : h->st.qkv)
+    if (p) hipFree(p);
+  h->st.qkv.clear();
+  if (h->st.tf_out) hipFree(h->st.tf_out);
+  if (h->st.z) hipFree(h->st.z);
+  h->st.tf_out = h->st.z = nullptr;
+  h->st.B = h->st.T = h->st.cap = 0;
+}
+
+// frames of transformer output to the left of a frame that its upsampled latents depend on (two stages of
+// [transposed conv k = stride, ConvNeXt with a causal depthwise k = 7])
+int upsampler_context_frames(const fmi_dac_config& c) {
+  int ctx = 0;
+  for (int i = 1; i >= 0; --i) ctx = cdiv(ctx + 6, c.downsample[1 - i]);
+  return ctx;
+}
+
+int copy_cols(fmi_dac* h, float* dst, int dst_ld, const float* src, int src_ld, int cols, int64_t rows) {
+  FMI_CHECK_HIP(hipMemcpy2DAsync(dst, (size_t)dst_ld * 4, src, (size_t)src_ld * 4, (size_t)cols * 4, (size_t)rows,
+                                 hipMemcpyDeviceToDevice, h->stream));
+  return FMI_OK;
+}
+
+// quantizer.decode for frames [t0, T) only, on top of the state of frames [0, t0) (t0 = 0: from scratch).  Same
+// kernels as run_quantizer_decode on the new columns; every one of them computes a column from its own inputs only
+// (k = 1 convs, column norms, RoPE by position, attention by query position), so z is bit-identical to the offline one.
+int run_quantizer_decode_inc(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0) {
+  const fmi_dac_config& c = h->cfg;
+  const Tf& tf = h->post;
+  const int C = tf.dim, F = tf.ffn, L0 = c.latent_dim, n = T - t0, cap = h->st.cap;
+  FMI_REQUIRE(C == L0, "post transformer width differs from the latent width");
+  FMI_REQUIRE(T <= h->rope_pos, "sequence of %d frames exceeds the RoPE table (%d)", T, h->rope_pos);
+  hipStream_t s = h->stream;
+  const int64_t peak = (int64_t)B * decode_peak_elems(c, T);
+  FMI_CHECK(ensure_buf(h, 0, peak));
+  FMI_CHECK(ensure_buf(h, 1, peak));
+  FMI_CHECK(ensure_buf(h, 2, (int64_t)B * C * n));
+  FMI_CHECK(ensure_buf(h, 3, (int64_t)B * 3 * C * n));
+  FMI_CHECK(ensure_buf(h, 4, (int64_t)B * 2 * F * n));
+  FMI_CHECK(ensure_buf(h, 5, (int64_t)B * F * n));
+  float *X = h->buf[0].p, *Y = h->buf[1].p;
+  float *nb = h->buf[2].p, *qkv = h->buf[3].p, *ab = h->buf[4].p, *act = h->buf[5].p;
+  FMI_CHECK(launch_clamp_indices(indices_dev, B, c.n_codebooks + 1, T, c.semantic_codebook_size, c.codebook_size, s));
+  // code embeddings of every frame (a gather), then the new columns as a compact [B][C][n]
+  FMI_CHECK(launch_lut_decode(indices_dev, h->lut, h->lut_off, c.n_codebooks, c.semantic_codebook_size, c.codebook_size,
+                              Y, B, L0, T, s));
+  FMI_CHECK(copy_cols(h, X, n, Y + t0, T, n, (int64_t)B * C));
+  for (size_t li = 0; li < tf.layers.size(); ++li) {
+    const TfLayer& L = tf.layers[li];
+    float* hist = h->st.qkv[li];
+    FMI_CHECK(launch_rmsnorm_cols(X, L.attn_norm, h->eps, nb, B, C, n, s));
+    FMI_CHECK(run_conv(h, L.wqkv, nb, qkv, B, n, nullptr, nullptr, nullptr, nullptr, ACT_NONE));
+    FMI_CHECK(launch_rope_cols(qkv, h->rope + (int64_t)t0 * h->head_dim, B, C, n, h->head_dim, s));
+    FMI_CHECK(copy_cols(h, hist + t0, cap, qkv, n, n, (int64_t)B * 3 * C));
+    FMI_CHECK(launch_window_attn(hist, nb, B, C, T, h->head_dim, tf.window, s, cap, t0));
+    FMI_CHECK(run_conv(h, L.wo, nb, X, B, n, nullptr, nullptr, X, L.g_attn, ACT_NONE));
+    FMI_CHECK(launch_rmsnorm_cols(X, L.ffn_norm, h->eps, nb, B, C, n, s));
+    FMI_CHECK(run_conv(h, L.w13, nb, ab, B, n, nullptr, nullptr, nullptr, nullptr, ACT_NONE));
+    FMI_CHECK(launch_silu_mul(ab, act, B, F, n, s));
+    FMI_CHECK(run_conv(h, L.w2, act, X, B, n, nullptr, nullptr, X, L.g_ffn, ACT_NONE));
+  }
+  FMI_CHECK(launch_rmsnorm_cols(X, tf.norm, h->eps, nb, B, C, n, s));
+  FMI_CHECK(copy_cols(h, h->st.tf_out + t0, cap, nb, n, n, (int64_t)B * C));
+  // upsampler over [t0 - cu, T): its first 4 cu output columns see a truncated left context and are dropped
+  const int cu = std::min(t0, upsampler_context_frames(c));
+  int len = cu + n;
+  FMI_CHECK(copy_cols(h, X, len, h->st.tf_out + (t0 - cu), cap, len, (int64_t)B * C));
+  for (int i = 0; i < 2; ++i) {
+    int l2;
+    FMI_CHECK(run_conv(h, h->up_conv[i], X, Y, B, len, &l2, nullptr, nullptr, nullptr, ACT_NONE));
+    std::swap(X, Y);
+    len = l2;
+    FMI_CHECK(run_convnext(h, h->up_cnx[i], X, B, L0, len));
+  }
+  const int up = len / (cu + n);
+  FMI_REQUIRE(up * (cu + n) == len && up == c.downsample[0] * c.downsample[1], "upsampler rate");
+  FMI_CHECK(copy_cols(h, h->st.z + (int64_t)up * t0, up * cap, X + (int64_t)up * cu, len, up * n, (int64_t)B * L0));
+  h->last_z = nullptr;
+  return FMI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -605,6 +696,7 @@ void fmi_dac_destroy(fmi_dac* h) {
   if (h->staging) hipFree(h->staging);
   for (auto p : h->pbuf)
     if (p) hipFree(p);
+  free_stream_state(h);
   hipEventDestroy(h->ev_in);
   hipEventDestroy(h->ev_out);
   hipStreamDestroy(h->stream);
@@ -768,6 +860,58 @@ int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, 
                                  (size_t)B * L0, hipMemcpyDeviceToDevice, s));
   FMI_CHECK(run_decoder(h, X, Y, B, w, audio_out_dev, 4 * ctx_frames));
   return sync_out(h, stream);
+}
+
+int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, int64_t stream_id,
+                               float* audio_out_dev, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h && indices_dev && audio_out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "codec weights not ready");
+  FMI_REQUIRE(B >= 1 && T >= 1 && t0 >= 0 && t0 < T, "bad frame range [%d, %d)", t0, T);
+  const fmi_dac_config& c = h->cfg;
+  const int L0 = c.latent_dim, C = h->post.dim, up = c.downsample[0] * c.downsample[1];
+  FMI_CHECK(sync_in(h, stream));
+  h->cur_planes = h->decode_planes;
+  hipStream_t s = h->stream;
+  // continue the state of the previous call, or start over (first call, other batch, a gap, buffers too small)
+  int from = t0;
+  if (!(h->st.B == B && h->st.id == stream_id && h->st.planes == h->cur_planes && h->st.T == t0 && t0 > 0 &&
+        T <= h->st.cap)) {
+    from = 0;
+    if (h->st.B != B || T > h->st.cap) {
+      FMI_CHECK_HIP(hipStreamSynchronize(s));
+      free_stream_state(h);
+      int cap = 1024;
+      while (cap < T) cap *= 2;
+      h->st.qkv.assign(h->post.layers.size(), nullptr);
+      for (auto& p : h->st.qkv) FMI_CHECK_HIP(hipMalloc((void**)&p, (size_t)B * 3 * C * cap * 4));
+      FMI_CHECK_HIP(hipMalloc((void**)&h->st.tf_out, (size_t)B * C * cap * 4));
+      FMI_CHECK_HIP(hipMalloc((void**)&h->st.z, (size_t)B * L0 * up * cap * 4));
+      h->st.B = B;
+      h->st.cap = cap;
+    }
+  }
+  h->st.T = 0;   // invalid until this call has succeeded
+  FMI_CHECK(run_quantizer_decode_inc(h, indices_dev, B, T, from));
+  const int ctx_frames = std::min(t0, cdiv(decoder_context_cols(c), up));
+  const int col_lo = up * (t0 - ctx_frames), w = up * T - col_lo;
+  float *X = h->buf[0].p, *Y = h->buf[1].p;
+  FMI_CHECK(copy_cols(h, X, w, h->st.z + col_lo, up * h->st.cap, w, (int64_t)B * L0));
+  FMI_CHECK(run_decoder(h, X, Y, B, w, audio_out_dev, up * ctx_frames));
+  h->st.T = T;
+  h->st.id = stream_id;
+  h->st.planes = h->cur_planes;
+  return sync_out(h, stream);
+}
+
+int fmi_dac_stream_reset(fmi_dac* h) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  free_stream_state(h);
+  return FMI_OK;
 }
 
 int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* audio_out_dev, void* stream) {

@@ -78,8 +78,9 @@ int launch_dwconv7(const float* x, const float* w /*[C][7]*/, const float* b, fl
 int launch_silu_mul(const float* ab /*[B][2F][L]*/, float* out /*[B][F][L]*/, int B, int F, int L, hipStream_t s);
 int launch_rope_cols(float* qkv /*[B][3C][L]*/, const bf16_t* table /*[L][hd/2][2]*/, int B, int C, int L, int hd,
                      hipStream_t s);
-int launch_window_attn(const float* qkv /*[B][3C][L]*/, float* out /*[B][C][L]*/, int B, int C, int L, int hd,
-                       int window, hipStream_t s);
+// ld: row stride of qkv (0 = L); only queries q_lo..L-1 are computed, out is the compact [B][C][L - q_lo]
+int launch_window_attn(const float* qkv /*[B][3C][ld]*/, float* out /*[B][C][L - q_lo]*/, int B, int C, int L, int hd,
+                       int window, hipStream_t s, int ld = 0, int q_lo = 0);
 int launch_lut_decode(const int64_t* idx /*[B][1+n][T]*/, const float* tables, const int* table_rows_off,
                       int n_books, int sem_size, int cb_size, float* out /*[B][C][T]*/, int B, int C, int T,
                       hipStream_t s);

@@ -864,19 +864,21 @@ int launch_rope_cols(float* qkv, const bf16_t* table, int B, int C, int L, int h
 
 // causal window-limited attention (modded_dac.py:380-398): query t sees keys max(0,t-w+1)..t.
 // one wave per (b, head, t); lanes run over keys (coalesced along time), head_dim <= 64.
+// qkv rows have stride ld (>= L: a persistent buffer of an incremental decode); only queries q_lo..L-1 are computed and
+// written to the compact out [B][C][L - q_lo].
 __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C,
-                                                          int L, int hd, int window) {
+                                                          int L, int hd, int window, int ld, int q_lo) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+  const int t = q_lo + blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
   if (t >= L) return;
-  const float* qb = qkv + ((int64_t)b * 3 * C + h * hd) * L;
-  const float* kb = qb + (int64_t)C * L;
-  const float* vb = kb + (int64_t)C * L;
+  const float* qb = qkv + ((int64_t)b * 3 * C + h * hd) * ld;
+  const float* kb = qb + (int64_t)C * ld;
+  const float* vb = kb + (int64_t)C * ld;
   const int lo = max(0, t - window + 1);
   const float scale = 1.0f / sqrtf((float)hd);
   float q[64];
 #pragma unroll
-  for (int d = 0; d < 64; ++d) q[d] = d < hd ? qb[(int64_t)d * L + t] : 0.f;
+  for (int d = 0; d < 64; ++d) q[d] = d < hd ? qb[(int64_t)d * ld + t] : 0.f;
   // pass 1: scores, running max
   float mx = -INFINITY;
   for (int j0 = lo; j0 <= t; j0 += 64) {
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
       float sc = 0.f;
 #pragma unroll
       for (int d = 0; d < 64; ++d)
-        if (d < hd) sc += q[d] * kb[(int64_t)d * L + j];
+        if (d < hd) sc += q[d] * kb[(int64_t)d * ld + j];
       mx = fmaxf(mx, sc * scale);
     }
   }
@@ -901,21 +903,22 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
       float sc = 0.f;
 #pragma unroll
       for (int d = 0; d < 64; ++d)
-        if (d < hd) sc += q[d] * kb[(int64_t)d * L + j];
+        if (d < hd) sc += q[d] * kb[(int64_t)d * ld + j];
       const float p = expf(sc * scale - mx);
       den += p;
 #pragma unroll
       for (int d = 0; d < 64; ++d)
-        if (d < hd) o[d] += p * vb[(int64_t)d * L + j];
+        if (d < hd) o[d] += p * vb[(int64_t)d * ld + j];
     }
   }
   den = wave_sum(den);
-  float* ob = out + ((int64_t)b * C + h * hd) * L + t;
+  const int lo_ = L - q_lo;
+  float* ob = out + ((int64_t)b * C + h * hd) * lo_ + (t - q_lo);
 #pragma unroll
   for (int d = 0; d < 64; ++d) {
     if (d < hd) {
       const float v = wave_sum(o[d]);
-      if (lane == 0) ob[(int64_t)d * L] = v / den;
+      if (lane == 0) ob[(int64_t)d * lo_] = v / den;
     }
   }
 }
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 // A query's result depends only on its own position, so it is invariant under batch, total length and tiling.
 template <int QT>
 __global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int C, int L, int window) {
+                                                              int C, int L, int window, int ld, int q_lo) {
   constexpr int HD = 64;
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   const int KT = QT + window - 1, RS = KT | 1;
@@ -938,20 +941,20 @@ __global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __res
   float* Qs = Vs + HD * RS;          // [QT][HD]
   float* Ps = Qs + QT * HD;          // [4][128]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int t0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
-  const float* qb = qkv + ((int64_t)b * 3 * C + h * HD) * L;
-  const float* kb = qb + (int64_t)C * L;
-  const float* vb = kb + (int64_t)C * L;
+  const int t0 = q_lo + blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
+  const float* qb = qkv + ((int64_t)b * 3 * C + h * HD) * ld;
+  const float* kb = qb + (int64_t)C * ld;
+  const float* vb = kb + (int64_t)C * ld;
   const int k0 = max(0, t0 - window + 1);
   const int nk = min(L, t0 + QT) - k0;
   for (int d = wave; d < HD; d += 4)
     for (int c = lane; c < nk; c += 64) {
-      Ks[d * RS + c] = kb[(int64_t)d * L + k0 + c];
-      Vs[d * RS + c] = vb[(int64_t)d * L + k0 + c];
+      Ks[d * RS + c] = kb[(int64_t)d * ld + k0 + c];
+      Vs[d * RS + c] = vb[(int64_t)d * ld + k0 + c];
     }
   for (int i = tid; i < QT * HD; i += 256) {
     const int d = i / QT, q = i % QT;
-    Qs[q * HD + d] = t0 + q < L ? qb[(int64_t)d * L + t0 + q] : 0.f;
+    Qs[q * HD + d] = t0 + q < L ? qb[(int64_t)d * ld + t0 + q] : 0.f;
   }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)HD);
@@ -987,12 +990,16 @@ __global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __res
     const float* vr = Vs + lane * RS + (lo - k0);  // lane = head dimension
     float o = 0.f;
     for (int jj = 0; jj < n; ++jj) o += pw[jj] * vr[jj];
-    out[((int64_t)b * C + h * HD + lane) * L + t] = o / den;
+    out[((int64_t)b * C + h * HD + lane) * (L - q_lo) + (t - q_lo)] = o / den;
   }
 }
 
-int launch_window_attn(const float* qkv, float* out, int B, int C, int L, int hd, int window, hipStream_t s) {
+int launch_window_attn(const float* qkv, float* out, int B, int C, int L, int hd, int window, hipStream_t s, int ld,
+                       int q_lo) {
   FMI_REQUIRE(hd <= 64 && C % hd == 0, "window_attn: head_dim %d unsupported", hd);
+  if (ld <= 0) ld = L;
+  FMI_REQUIRE(ld >= L && q_lo >= 0 && q_lo < L, "window_attn: bad stride / query range");
+  const int nq = L - q_lo;
   constexpr int QT = 16;
   const size_t smem = (size_t)(2 * 64 * ((QT + window - 1) | 1) + QT * 64 + 4 * 128) * sizeof(float);
   static const bool lds_off = []() { const char* e = getenv("FMI_WATTN_OLD"); return e && atoi(e) != 0; }();
@@ -1000,12 +1007,12 @@ int launch_window_attn(const float* qkv, float* out, int B, int C, int L, int hd
     if (smem > 64 * 1024)
       FMI_CHECK_HIP(hipFuncSetAttribute((const void*)window_attn_lds_kernel<QT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)smem));
-    hipLaunchKernelGGL((window_attn_lds_kernel<QT>), dim3(cdiv(L, QT), C / hd, B), dim3(256), smem, s, qkv, out, C, L,
-                       window);
+    hipLaunchKernelGGL((window_attn_lds_kernel<QT>), dim3(cdiv(nq, QT), C / hd, B), dim3(256), smem, s, qkv, out, C, L,
+                       window, ld, q_lo);
     FMI_CHECK_HIP(hipGetLastError());
     return FMI_OK;
   }
-  hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(L, 4), C / hd, B), dim3(256), 0, s, qkv, out, C, L, hd, window);
+  hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nq, 4), C / hd, B), dim3(256), 0, s, qkv, out, C, L, hd, window, ld, q_lo);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }

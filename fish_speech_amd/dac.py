@@ -10,6 +10,7 @@ kernels of csrc/dac_kernels.hip; torch is used for buffers and for folding weigh
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import math
 import threading
 from dataclasses import dataclass
@@ -367,8 +368,11 @@ class MiDAC:
     # ---- incremental decode for streaming: audio of frames [t0, T) given all codes so far.  Bit-identical to
     # from_indices(final codes)[..., t0*frame_length : T*frame_length] because every codec layer is causal
     # (modded_dac.py:521-588; window mask 380-398).  `indices` is clamped in place like from_indices.
+    # stream_id: keep the quantizer side (per-layer K/V of the windowed transformer, its output, the upsampled
+    # latents) of frames [0, t0) on the device between the calls of ONE stream (fmi_dac_decode_tail_cached): the
+    # caller promises that the codes of frames [0, t0) are those of its previous call with this id.
     @torch.no_grad()
-    def from_indices_tail(self, indices: torch.Tensor, t0: int) -> torch.Tensor:
+    def from_indices_tail(self, indices: torch.Tensor, t0: int, stream_id: Optional[int] = None) -> torch.Tensor:
         work = indices.to(device=self.device, dtype=torch.int64).contiguous()
         B, nb, T = work.shape
         if nb != self.config.n_codebooks + 1:
@@ -376,10 +380,24 @@ class MiDAC:
         if not 0 <= t0 < T:
             raise ValueError(f"t0={t0} outside [0, {T})")
         out = torch.empty(B, 1, (T - t0) * self.frame_length, dtype=torch.float32, device=self.device)
-        self._decode_call(self.lib.fmi_dac_decode_tail, C.c_void_p(work.data_ptr()), B, T, int(t0),
-                          C.c_void_p(out.data_ptr()), self._stream())
+        if stream_id is None:
+            self._decode_call(self.lib.fmi_dac_decode_tail, C.c_void_p(work.data_ptr()), B, T, int(t0),
+                              C.c_void_p(out.data_ptr()), self._stream())
+        else:
+            self._decode_call(self.lib.fmi_dac_decode_tail_cached, C.c_void_p(work.data_ptr()), B, T, int(t0),
+                              C.c_int64(int(stream_id)), C.c_void_p(out.data_ptr()), self._stream())
         self._keep = work
         return out
+
+    _stream_ids = itertools.count(1)
+
+    @classmethod
+    def new_stream_id(cls) -> int:
+        return next(cls._stream_ids)
+
+    def stream_reset(self) -> None:
+        """free the device state kept for from_indices_tail(stream_id=...)"""
+        check(self.lib.fmi_dac_stream_reset(self._h))
 
     @property
     def context_frames(self) -> int:

@@ -10,9 +10,10 @@ granularity.  What is emitted is exactly what the offline path produces:
 
 * codes: the frames ``generate_batch`` yields (same slots, same graph-replayed kernels);
 * audio: every codec layer is causal (modded_dac.py:521-588, window mask 380-398), so the samples of
-  frames [t0, t1) do not depend on later frames; ``MiDAC.from_indices_tail`` recomputes them from the
-  codes so far and the concatenation of all chunks is bit-identical to ``from_indices`` over the final
-  codes (tests/test_stream_gpu.py).
+  frames [t0, t1) do not depend on later frames; ``MiDAC.from_indices_tail`` computes them from the new
+  codes and the state it kept of the earlier frames (per-layer K/V of the windowed transformer, its output, the
+  upsampled latents; the decoder conv stack re-reads 5 frames of left context) and the concatenation of all chunks
+  is bit-identical to ``from_indices`` over the final codes (tests/test_stream_gpu.py).
 
 Like ``generate_long`` (inference.py:708, ``codes = y[1:, T:-1]``) the last generated frame of an
 utterance -- the ``<|im_end|>`` frame, or the one that hit ``max_new_tokens`` -- is never voiced, so the
@@ -78,6 +79,7 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
     total = max(mn)
     generated = 1
     emitted = 0
+    stream_id = codec.new_stream_id()                  # the codec keeps its quantizer-side state between our calls
     length = [None] * n                                # final frame count of an utterance once it ended
     try:
         for mark in chunk_schedule(total, first_chunk_frames + 1, chunk_frames):
@@ -95,7 +97,7 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
             if t1 > emitted:
                 frames = model.frames_device(n, t1)                       # (B, t1, 1+ncb) int32
                 codes = frames[:, :, 1:].permute(0, 2, 1).to(torch.int64).contiguous()
-                audio = codec.from_indices_tail(codes, emitted)
+                audio = codec.from_indices_tail(codes, emitted, stream_id=stream_id)
                 yield StreamChunk(emitted, t1, audio, codes[:, :, emitted:t1],
                                   [max(0, min(v, t1) - emitted) for v in voiced], finished)
                 emitted = t1

@@ -256,6 +256,18 @@ int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_
 int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, float* audio_out_dev,
                         void* stream);
 int fmi_dac_context_frames(const fmi_dac* h);
+/* The same samples with the quantizer side kept ACROSS calls (the engine's segment loop,
+ * fish_speech/inference_engine/__init__.py:73-140, cut at frame granularity): the roped q|k|v of every layer of the
+ * windowed post-transformer, its output and the upsampled latents of frames [0, t0) stay on the device, and only the
+ * columns of frames [t0, T) run through LUT -> transformer (attention over the cached keys) -> upsampler (5 frames of
+ * left context) -> decoder (fmi_dac_context_frames() of left context).  Bit-identical to fmi_dac_decode_tail.
+ * The state is continued when (stream_id, B) equal the previous call's and t0 equals its T -- the caller promises that
+ * the codes of frames [0, t0) are the ones it passed before; any other call recomputes frames [0, T) and restarts the
+ * state (so interleaved streams stay correct, they only lose the saving).  State: 9 x B x 3 x latent x capacity x 4
+ * bytes (capacity = 1024 frames, doubled on demand); fmi_dac_stream_reset frees it. */
+int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, int64_t stream_id,
+                               float* audio_out_dev, void* stream);
+int fmi_dac_stream_reset(fmi_dac* h);
 /* DAC.decode (modded_dac.py:929-946): latent z fp32 (B, latent_dim, L) -> audio fp32 (B,1,L*hop_length). */
 int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* audio_out_dev, void* stream);
 /* DAC.encode (modded_dac.py:874-923): audio fp32 (B,1,N) (N already padded to a multiple of

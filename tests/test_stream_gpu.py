@@ -57,6 +57,65 @@ def test_tail_decode_concatenates_to_the_full_decode_bitwise_full_size(full_code
     _tail_chunks_equal_full(cfg, codec, 2, 48, [3, 4, 9, 33], seed=4)
 
 
+def _cached_chunks_equal_full(cfg, codec, B, T, cuts, seed, sid):
+    codes = D.make_codes(cfg, B, T, seed=seed).to(DEV)
+    want = codec.from_indices(codes.clone())
+    pieces, t0 = [], 0
+    for t1 in list(cuts) + [T]:
+        pieces.append(codec.from_indices_tail(codes[:, :, :t1].clone(), t0, stream_id=sid))
+        t0 = t1
+    got = torch.cat(pieces, dim=-1)
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def test_cached_tail_decode_is_bit_identical_and_survives_interleaving(small_codec, full_codec):
+    """from_indices_tail(stream_id=...): the quantizer side of frames [0, t0) comes from the state of the previous call
+    (per-layer K/V of the windowed transformer, its output, the upsampled latents).  Chunks shorter and longer than
+    the upsampler's (5 frames) and the transformer's (window) context; a second stream with the SAME chunk marks
+    interleaved on the same codec (its calls restart the state: correct, only slower); a gap in t0; a batch change."""
+    for cfg, _, codec in (small_codec, full_codec):
+        sid = codec.new_stream_id()
+        _cached_chunks_equal_full(cfg, codec, 2, 48, [1, 2, 7, 8, 20, 47], seed=5, sid=sid)
+        _cached_chunks_equal_full(cfg, codec, 2, 30, [9], seed=6, sid=codec.new_stream_id())
+        # two interleaved streams, same marks
+        a = D.make_codes(cfg, 2, 40, seed=7).to(DEV)
+        b = D.make_codes(cfg, 2, 40, seed=8).to(DEV)
+        wa, wb = codec.from_indices(a.clone()), codec.from_indices(b.clone())
+        ia, ib = codec.new_stream_id(), codec.new_stream_id()
+        pa, pb, t0 = [], [], 0
+        for t1 in (9, 24, 40):
+            pa.append(codec.from_indices_tail(a[:, :, :t1].clone(), t0, stream_id=ia))
+            pb.append(codec.from_indices_tail(b[:, :, :t1].clone(), t0, stream_id=ib))
+            t0 = t1
+        assert torch.equal(torch.cat(pa, -1), wa) and torch.equal(torch.cat(pb, -1), wb)
+        # a call that does not continue the state (gap), then one with another batch size
+        fl = cfg.frame_length
+        got = codec.from_indices_tail(a[:, :, :33].clone(), 30, stream_id=ia)
+        assert torch.equal(got, wa[..., 30 * fl:33 * fl])
+        got = codec.from_indices_tail(a[:1, :, :36].clone(), 33, stream_id=ia)
+        assert torch.equal(got, codec.from_indices(a[:1].clone())[..., 33 * fl:36 * fl])
+        codec.stream_reset()
+        got = codec.from_indices_tail(a[:, :, :12].clone(), 3, stream_id=ia)
+        assert torch.equal(got, wa[..., 3 * fl:12 * fl])
+    codec.stream_reset()
+
+
+def test_cached_tail_decode_long_stream_full_size(full_codec):
+    """beyond the attention window (tf_window frames) and across a capacity doubling (1024 frames)"""
+    cfg, _, codec = full_codec
+    T = 1100
+    codes = D.make_codes(cfg, 1, T, seed=9).to(DEV)
+    want = codec.from_indices(codes.clone())
+    sid = codec.new_stream_id()
+    fl = cfg.frame_length
+    t0 = 0
+    for t1 in (8, 40, 200, 500, 1000, 1030, T):
+        got = codec.from_indices_tail(codes[:, :, :t1].clone(), t0, stream_id=sid)
+        assert torch.equal(got, want[..., t0 * fl:t1 * fl]), (t0, t1)
+        t0 = t1
+    codec.stream_reset()
+
+
 def test_tail_decode_matches_oracle(full_codec):
     cfg, state, codec = full_codec
     codes = D.make_codes(cfg, 1, 12, seed=8)
