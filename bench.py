@@ -91,8 +91,9 @@ def make_prompts(cfg, n, base_seed):
     return ps
 
 
-def algorithmic_bytes_per_frame(cfg, batch, mean_ctx):
-    """bf16 weight bytes streamed once per frame step + per-utterance KV reads."""
+def algorithmic_bytes_per_frame(cfg, batch, mean_ctx, int8=False):
+    """weight bytes streamed once per frame step (bf16; int8 + a bf16 scale per row for --int8) +
+    per-utterance KV reads (bf16)."""
     d, ffn = cfg.dim, cfg.intermediate_size
     qkv = (cfg.n_head + 2 * cfg.n_local_heads) * cfg.head_dim
     per_layer = qkv * d + d * cfg.n_head * cfg.head_dim + 3 * ffn * d
@@ -104,6 +105,9 @@ def algorithmic_bytes_per_frame(cfg, batch, mean_ctx):
     n_live = cfg.semantic_end_id - cfg.semantic_begin_id + 2
     heads = n_live * d + (cfg.num_codebooks - 1) * cfg.codebook_size * d
     kv = batch * cfg.n_layer * 2 * cfg.n_local_heads * cfg.head_dim * mean_ctx
+    if int8:   # one byte per weight, two per output row (scale); rows ~ weights / d
+        w = slow + fast + heads
+        return w + 2 * (w // d) + 2 * kv
     return 2 * (slow + fast + heads + kv)
 
 
@@ -443,7 +447,7 @@ def main():
 
     audio_s = world * BATCH * N_FRAMES * FRAME_LEN / SAMPLE_RATE * args.steps
     mean_ctx = PROMPT_T + N_FRAMES / 2
-    bytes_frame = algorithmic_bytes_per_frame(cfg, BATCH, mean_ctx)
+    bytes_frame = algorithmic_bytes_per_frame(cfg, BATCH, mean_ctx, int8=args.int8)
     avg_frame_s = (sum(frame_ms) / len(frame_ms)) * 1e-3
     achieved = bytes_frame / avg_frame_s / 1e9
     out = {
@@ -467,7 +471,7 @@ def main():
                          "codec_decode_batch": round(sum(codec_ms) / len(codec_ms), 2) if codec_ms else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 4),
-                     "traffic": PMC_FETCH_BYTES_PER_FRAME if (N_FRAMES == 215 and BATCH == 8) else None,
+                     "traffic": PMC_FETCH_BYTES_PER_FRAME if (N_FRAMES == 215 and BATCH == 8 and not args.int8) else None,
                      "kernel": "decode frame: 302 linear_skinny_kernel launches (weight streaming) + 36 attention, 40 fast-attention, "
                                "10 sampler launches, replayed as one hipGraph",
                      "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},

@@ -311,6 +311,17 @@ int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf
 
 __device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
+// float(int8 in byte BYTE of w): byte select and sign extension are SDWA operand modifiers of the convert itself
+template <int BYTE>
+__device__ inline float cvt_i8_f32(uint32_t w) {
+  float r;
+  if constexpr (BYTE == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(w));
+  else if constexpr (BYTE == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(w));
+  else if constexpr (BYTE == 2) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(w));
+  else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(w));
+  return r;
+}
+
 template <bool NT>
 __device__ inline u32x4 wload(const u32x4* p) {
   if (NT) return __builtin_nontemporal_load(p);
@@ -364,15 +375,24 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
         }
       }
   };
-  // int8 pair register (tile 0's 8 values | tile 1's 8 values) -> the two bf16 A operands
+  // int8 pair register (tile 0's 8 values | tile 1's 8 values) -> the two bf16 A operands.  One SDWA convert per
+  // weight (byte select + sign extension inside v_cvt_f32_i32) and one pack per two: the compiler's own sequence for
+  // (float)(int8_t)(w >> 8n) is shift + v_bfe_i32 + convert, 3.5 VALU instructions per weight against 1.5.
   auto unpack_q8 = [](const u32x4& q, u32x4& lo, u32x4& hi) {
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       const uint32_t w0 = q[d], w1 = q[2 + d];
+#ifdef FMI_Q8_PLAIN_CVT
       lo[2 * d] = cvt_pk_bf16((float)(int8_t)(w0), (float)(int8_t)(w0 >> 8));
       lo[2 * d + 1] = cvt_pk_bf16((float)(int8_t)(w0 >> 16), (float)(int8_t)(w0 >> 24));
       hi[2 * d] = cvt_pk_bf16((float)(int8_t)(w1), (float)(int8_t)(w1 >> 8));
       hi[2 * d + 1] = cvt_pk_bf16((float)(int8_t)(w1 >> 16), (float)(int8_t)(w1 >> 24));
+#else
+      lo[2 * d] = cvt_pk_bf16(cvt_i8_f32<0>(w0), cvt_i8_f32<1>(w0));
+      lo[2 * d + 1] = cvt_pk_bf16(cvt_i8_f32<2>(w0), cvt_i8_f32<3>(w0));
+      hi[2 * d] = cvt_pk_bf16(cvt_i8_f32<0>(w1), cvt_i8_f32<1>(w1));
+      hi[2 * d + 1] = cvt_pk_bf16(cvt_i8_f32<2>(w1), cvt_i8_f32<3>(w1));
+#endif
     }
   };
   if (nfull > 0) load_chunk(pbeg);
@@ -568,14 +588,18 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   const int KT = a.K / 32;
   const int ntile = a.N / 16;
   if (a.wq && a.M <= 8 && a.K % 64 == 0 && KT >= 32) {
-    // int8 stream: a pair is 1 KiB instead of 2, so twice the pairs are kept in flight -- what bounds the kernel
-    // is cache lines in flight per CU, and with the bf16 depth the int8 stream was no faster than bf16
-    if (a.epi == EPI_SILU) return launch_skinny_t<8, 2, 2>(a, s);
+    // int8 stream (tools/gemv_q8_bench.hip, profiles/r02_gemv_q8.txt).  The wave count stays 8 -- the split-K
+    // boundaries, hence the result bits, equal the bf16 kernel on the dequantised weights; pairs in flight and tiles
+    // per work-group do not change the order of accumulation.  us, int8 vs bf16: w1|w3 15.4 vs 21.1, wqkv 8.9 vs 10.3,
+    // wo 5.9 vs 7.4, w2 11.0 vs 14.7, heads 7.2 vs 8.4 -- once the int8 -> bf16 conversion is one SDWA convert per
+    // weight; with the compiler's shift + bfe + convert sequence the kernel was VALU-bound and no faster than bf16.
+    if (a.epi == EPI_SILU) return launch_skinny_t<8, 1, 2>(a, s);
     if (a.norm_w) {
-      if (ntile % 2 == 0 && ntile > 320) return launch_skinny_t<8, 2, 2>(a, s);
-      return launch_skinny_t<8, 4, 1>(a, s);
+      if (ntile % 2 == 0 && ntile > 320) return launch_skinny_t<8, 4, 2>(a, s);
+      return launch_skinny_t<8, 2, 1>(a, s);
     }
-    return launch_skinny_t<8, 4, 1>(a, s);
+    if (a.K <= 4096) return launch_skinny_t<8, 4, 1>(a, s);
+    return launch_skinny_t<8, 2, 1>(a, s);
   }
   if (KT < 32) {  // tiny test models
     if (a.epi == EPI_SILU || ntile % 2 == 0) return launch_skinny_t<4, 1, 2>(a, s);
