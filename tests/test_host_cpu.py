@@ -1,0 +1,262 @@
+"""Host-side logic above the C ABI on the CPU, with stand-ins for the two device objects: the streaming schedule
+(stream.generate_stream), the engine's InferenceResult protocol (engine.py; reference:
+fish_speech/inference_engine/__init__.py:73-140, utils.py), the HTTP byte stream (tools/server/inference.py:12-45) and
+the server's batch codec helpers (tools/server/model_utils.py:15-86).  The stand-ins implement exactly the slot API /
+codec API those modules call; the GPU runs of the same code are in tests/test_stream_gpu.py."""
+import io
+import itertools
+import wave
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from fish_speech_amd import server_utils
+from fish_speech_amd.engine import InferenceResult, StreamingTTSEngine, TTSRequest, inference_wrapper, wav_chunk_header
+from fish_speech_amd.stream import chunk_schedule, generate_stream
+from oracle.fake_tokenizer import ByteTokenizer
+
+NCB = 9
+
+
+class StubDualAR:
+    """MiDualAR's slot API with a deterministic generator: utterance with seed s has 4 + (13 s) % 37 frames (its last
+    one is the <|im_end|> frame) unless max_new_tokens cuts it; frame f holds codes (7 s + 3 f + c) % 1024."""
+
+    def __init__(self, max_batch=4, max_seq_len=4096):
+        self.config = SimpleNamespace(num_codebooks=NCB, max_seq_len=max_seq_len)
+        self.max_batch_size, self._cache_setup_done = max_batch, True
+        self.tokenizer = ByteTokenizer()
+        self.slots, self._seed = {}, itertools.count(100)
+        self.released = []
+
+    def next_seed(self):
+        return next(self._seed)
+
+    def _sampling(self, t, p, k, seed, ras):
+        return seed
+
+    @staticmethod
+    def natural_len(seed):
+        return 4 + (13 * seed) % 37
+
+    def prefill(self, slots, prompts, max_new, samp):
+        for s, m, seed in zip(slots, max_new, samp):
+            assert s not in self.slots
+            self.slots[s] = dict(seed=seed, limit=min(m, self.natural_len(seed)), eos=self.natural_len(seed) <= m, n=1)
+
+    def decode(self, slots, n_frames):
+        for s in slots:
+            st = self.slots[s]
+            st["n"] = min(st["limit"], st["n"] + n_frames)
+
+    def poll_done(self, slots):
+        return [1 if (self.slots[s]["eos"] and self.slots[s]["n"] >= self.slots[s]["limit"]) else 0 for s in slots]
+
+    def _frames(self, seed, n):
+        f = torch.arange(n).view(-1, 1)
+        c = torch.arange(NCB + 1).view(1, -1)
+        return ((7 * seed + 3 * f + c) % 1024).to(torch.int32)
+
+    def read(self, slot):
+        st = self.slots[slot]
+        return self._frames(st["seed"], st["n"]), 1
+
+    def frames_device(self, n_slots, n_frames):
+        out = torch.zeros(n_slots, n_frames, NCB + 1, dtype=torch.int32)
+        for s in range(n_slots):
+            k = min(n_frames, self.slots[s]["n"])
+            out[s, :k] = self._frames(self.slots[s]["seed"], k)
+        return out
+
+    def release(self, slot):
+        self.released.append(slot)
+        del self.slots[slot]
+
+    def expected_codes(self, seed, max_new):
+        """what generate_long keeps of an utterance: codes[1:, T:-1] (the last generated frame is never voiced)"""
+        n = min(max_new, self.natural_len(seed))
+        return self._frames(seed, n)[: n - 1, 1:].t().to(torch.int64)
+
+
+class StubCodec:
+    """MiDAC's decode API with a causal stand-in: sample j of frame t = (sum of the frame's codes + 0.001 t) * 1e-4 + 1e-7 j."""
+    frame_length, sample_rate, device = 16, 44100, torch.device("cpu")
+
+    def __init__(self):
+        self.calls = []
+        self._ids = itertools.count(1)
+
+    def new_stream_id(self):
+        return next(self._ids)
+
+    def from_indices(self, codes):
+        B, nb, T = codes.shape
+        assert nb == NCB + 1 or nb == NCB
+        base = (codes.sum(1).double() + 0.001 * torch.arange(T).double()) * 1e-4          # (B, T)
+        j = torch.arange(self.frame_length).double() * 1e-7
+        return (base[:, :, None] + j).reshape(B, 1, T * self.frame_length).float()
+
+    def from_indices_tail(self, codes, t0, stream_id=None):
+        self.calls.append((codes.shape[-1], t0, stream_id))
+        return self.from_indices(codes)[..., t0 * self.frame_length:]
+
+    def encode(self, padded, audio_lengths=None):
+        B, _, N = padded.shape
+        T = -(-N // self.frame_length)
+        feats = torch.zeros(B, NCB + 1, T, dtype=torch.int64)
+        for b in range(B):
+            feats[b] = (padded[b, 0, :: self.frame_length][:T] * 1000).round().long().clamp(0, 1023)[None]
+        return feats, torch.tensor([-(-int(n) // self.frame_length) for n in audio_lengths])
+
+
+def test_chunk_schedule():
+    assert chunk_schedule(215, 8, 32) == [8, 40, 72, 104, 136, 168, 200, 215]
+    assert chunk_schedule(5, 8, 32) == [5]
+    assert chunk_schedule(8, 8, 32) == [8]
+    assert chunk_schedule(9, 8, 1) == [8, 9]
+    with pytest.raises(ValueError):
+        chunk_schedule(10, 0, 4)
+    with pytest.raises(ValueError):
+        chunk_schedule(10, 4, 0)
+
+
+@pytest.mark.parametrize("first,chunk", [(8, 32), (1, 1), (3, 5), (64, 64)])
+def test_generate_stream_emits_exactly_the_offline_frames(first, chunk):
+    """Ragged batch (utterances end at 17, 30, 6 and -- cut by max_new_tokens -- 20 frames): per utterance the
+    concatenation of the valid parts of all chunks is from_indices over codes[1:, T:-1]; the newest frame of a live
+    utterance is held back; chunks continue one codec stream (t0 of a call = T of the previous one, same id); every
+    slot is released."""
+    model, codec = StubDualAR(max_batch=4), StubCodec()
+    seeds = [1, 2, 3, 4]           # natural lengths 17, 30, 6, 19
+    assert [model.natural_len(s) for s in seeds] == [17, 30, 6, 19]
+    prompts = [torch.zeros(NCB + 1, 5 + i, dtype=torch.int64) for i in range(4)]
+    max_new = 20
+    audio = [[] for _ in seeds]
+    codes = [[] for _ in seeds]
+    last_t1 = 0
+    for ch in generate_stream(model=model, codec=codec, prompts=prompts, max_new_tokens=max_new,
+                              first_chunk_frames=first, chunk_frames=chunk, seeds=seeds):
+        assert ch.t0 == last_t1 and ch.t1 > ch.t0
+        last_t1 = ch.t1
+        for i, v in enumerate(ch.valid_frames):
+            assert 0 <= v <= ch.t1 - ch.t0
+            audio[i].append(ch.audio[i, :, : v * codec.frame_length])
+            codes[i].append(ch.codes[i, :, :v])
+    for i, s in enumerate(seeds):
+        want_codes = model.expected_codes(s, max_new)
+        got_codes = torch.cat(codes[i], dim=1)
+        assert torch.equal(got_codes, want_codes), i
+        want = codec.from_indices(want_codes[None])[0]
+        assert torch.equal(torch.cat(audio[i], dim=-1), want), i
+    assert sorted(model.released) == [0, 1, 2, 3] and not model.slots
+    # one codec stream: same id, contiguous, starts at 0
+    ids = {c[2] for c in codec.calls}
+    assert len(ids) == 1 and None not in ids
+    assert codec.calls[0][1] == 0
+    for a, b in zip(codec.calls, codec.calls[1:]):
+        assert b[1] == a[0]
+
+
+def test_generate_stream_argument_errors():
+    model, codec = StubDualAR(max_batch=2, max_seq_len=64), StubCodec()
+    p = torch.zeros(NCB + 1, 5, dtype=torch.int64)
+    with pytest.raises(ValueError, match="exceeds max_seq_len"):
+        list(generate_stream(model=model, codec=codec, prompts=[torch.zeros(NCB + 1, 64, dtype=torch.int64)], max_new_tokens=4))
+    with pytest.raises(ValueError, match="exceeds max_batch_size"):
+        list(generate_stream(model=model, codec=codec, prompts=[p, p, p], max_new_tokens=4))
+    with pytest.raises(ValueError):
+        list(generate_stream(model=model, codec=codec, prompts=[p], max_new_tokens=4, chunk_frames=0))
+    assert not model.slots            # released even though the generator raised
+
+
+def test_wav_chunk_header_is_an_empty_wav_file():
+    h = wav_chunk_header(sample_rate=44100)
+    with wave.open(io.BytesIO(h), "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 44100, 0)
+    assert len(h) == 44
+
+
+def test_engine_protocol_and_byte_stream():
+    """header (streaming only) -> segments -> final; the segments concatenate to the final audio, which is the codec's
+    decode of the codes the offline path keeps; two text chunks give two generations whose second prompt carries the
+    first one's codes; the HTTP wrapper scales segments to int16 bytes."""
+    model, codec = StubDualAR(max_batch=1), StubCodec()
+    eng = StreamingTTSEngine(model, codec, precision=None)
+    req = TTSRequest(text="hello there", streaming=True, max_new_tokens=64, seed=3, first_chunk_frames=2, chunk_frames=3)
+    res = list(eng.inference(req))
+    assert [r.code for r in res[:1]] == ["header"] and res[-1].code == "final"
+    assert all(r.code == "segment" for r in res[1:-1]) and len(res) >= 4
+    assert bytes(res[0].audio[1].tobytes()) == wav_chunk_header(sample_rate=codec.sample_rate)
+    segs = np.concatenate([r.audio[1] for r in res[1:-1]])
+    assert np.array_equal(segs, res[-1].audio[1]) and res[-1].audio[0] == codec.sample_rate
+    want = codec.from_indices(model.expected_codes(3, 64)[None])[0, 0].numpy()
+    assert np.array_equal(res[-1].audio[1], want)
+    # not streaming: only the final result
+    res2 = list(eng.inference(TTSRequest(text="hello there", streaming=False, max_new_tokens=64, seed=3)))
+    assert [r.code for r in res2] == ["final"] and np.array_equal(res2[0].audio[1], want)
+    # byte stream of the HTTP endpoint
+    chunks = list(inference_wrapper(req, eng))
+    assert bytes(chunks[0].tobytes()) == wav_chunk_header(sample_rate=codec.sample_rate)
+    pcm = b"".join(chunks[1:-1])
+    assert pcm == (want * 32768).astype(np.int16).tobytes()
+    assert np.array_equal(chunks[-1], want)
+
+
+def test_engine_reports_errors_as_results():
+    model, codec = StubDualAR(max_batch=1, max_seq_len=2100), StubCodec()
+    eng = StreamingTTSEngine(model, codec, precision=None)
+    # prompt longer than max_seq_len - 2048 (text2semantic/inference.py:658-661)
+    res = list(eng.inference(TTSRequest(text="x" * 200, max_new_tokens=8, seed=1)))
+    assert [r.code for r in res] == ["error"] and "too long" in str(res[0].error)
+    with pytest.raises(RuntimeError, match="too long"):
+        list(inference_wrapper(TTSRequest(text="x" * 200, max_new_tokens=8, seed=1), eng))
+    # an utterance of one frame has no voiced frame at all
+    one = StubDualAR(max_batch=1)
+    res = list(StreamingTTSEngine(one, codec, precision=None).inference(TTSRequest(text="hi", max_new_tokens=1, seed=1)))
+    assert [r.code for r in res] == ["error"] and "No audio generated" in str(res[0].error)
+    assert not model.slots and not one.slots
+
+
+def _wav_bytes(x, sr):
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(sr)
+        f.writeframes((np.clip(x, -1, 1) * 32767).astype(np.int16).tobytes())
+    return buf.getvalue()
+
+
+def test_server_batch_helpers_pad_trim_and_cache():
+    codec = StubCodec()
+    # decode: ragged code matrices, more items than one micro-batch
+    feats = [torch.randint(0, 1024, (NCB + 1, t), generator=torch.Generator().manual_seed(t)) for t in (5, 1, 9, 3, 7, 2, 8, 4, 6, 11)]
+    outs = server_utils.batch_vqgan_decode(codec, feats)
+    assert len(outs) == len(feats) > server_utils.MICRO_BATCH_SIZE
+    for f, o in zip(feats, outs):
+        assert o.shape == (1, f.shape[-1] * codec.frame_length)
+        assert np.array_equal(o, codec.from_indices(f[None])[0].numpy())
+    # encode: tensors and wav bytes (one at another sample rate), trimmed to each item's frames
+    t = np.linspace(0, 1, 4410, endpoint=False)
+    a0 = torch.from_numpy((0.3 * np.sin(2 * np.pi * 50 * t)).astype(np.float32))[None]
+    wav_same = _wav_bytes(0.25 * np.ones(1000), 44100)
+    wav_half = _wav_bytes(0.5 * np.ones(600), 22050)
+    res = server_utils.batch_encode(codec, [a0, wav_same, wav_half])
+    assert [r.shape for r in res] == [(NCB + 1, -(-4410 // 16)), (NCB + 1, -(-1000 // 16)), (NCB + 1, -(-1200 // 16))]
+    assert int(res[1][0, 3]) == 250 and abs(int(res[2][0, 10]) - 500) <= 2      # resampled to 44.1 kHz
+    # LRU keyed by the byte strings
+    server_utils._cache.clear()
+    n_before = len(codec.calls)
+    r1 = server_utils.cached_vqgan_batch_encode(codec, [wav_same])
+    r2 = server_utils.cached_vqgan_batch_encode(codec, [wav_same])
+    assert r1 is r2 and len(server_utils._cache) == 1 and len(codec.calls) == n_before
+    server_utils.cached_vqgan_batch_encode(codec, [wav_half])
+    assert len(server_utils._cache) == 2
+    server_utils._cache.clear()
+
+
+def test_inference_result_dataclass_matches_the_reference_fields():
+    r = InferenceResult(code="final", audio=(44100, np.zeros(2, np.float32)), error=None)
+    assert (r.code, r.error) == ("final", None) and r.audio[0] == 44100
