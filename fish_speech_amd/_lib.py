@@ -64,6 +64,8 @@ _SIGS = {
     "fmi_dualar_poll_done": (C.c_int, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "fmi_dualar_release": (C.c_int, [_P, _I]),
     "fmi_dualar_out_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I)]),
+    "fmi_dualar_wait": (C.c_int, [_P, _P]),
+    "fmi_dualar_synchronize": (C.c_int, [_P]),
     "fmi_dualar_step": (C.c_int, [_P, _I, _P, _I, _I, C.POINTER(SamplingC), _P, C.c_int32, _P, _P]),
     "fmi_dualar_forward_slow": (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P]),
     "fmi_dualar_forward_fast": (C.c_int, [_P, _I, _P, _I, _P, _P]),

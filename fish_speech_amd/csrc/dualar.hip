@@ -80,6 +80,8 @@ struct fmi_dualar {
   int max_top_k = 0;  // largest top_k over the LIVE slots (selects the sampler variant the graphs embed)
   std::vector<int> slot_top_k;  // per slot, 0 = released
   std::map<int, hipGraphExec_t> graphs;
+  bool out_pending = false;             // frames of a decode call the caller's stream has not been ordered after
+  std::vector<int32_t> row_slot_host;   // what ws.row_slot[0..n) holds on the device (empty: unknown)
   void* staging = nullptr;
   size_t staging_bytes = 0;
   float last_ms = 0.f;
@@ -198,6 +200,7 @@ int sync_in(fmi_dualar* h, void* user_stream) {
 int sync_out(fmi_dualar* h, void* user_stream) {
   FMI_CHECK_HIP(hipEventRecord(h->ev_out, h->stream));
   FMI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)user_stream, h->ev_out, 0));
+  h->out_pending = false;
   return FMI_OK;
 }
 
@@ -848,6 +851,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
     slots[i] = slot_ids[i];
   }
   Workspace& ws = h->ws;
+  h->row_slot_host.clear();
   FMI_CHECK_HIP(hipMemcpyAsync(ws.row_slot, row_slot.data(), rows * 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipMemcpyAsync(ws.row_pos, row_pos.data(), rows * 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipMemcpyAsync(ws.last_rows, last.data(), n * 4, hipMemcpyHostToDevice, s));
@@ -868,6 +872,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
   // the tail addresses slots through row_slot[0..n)
   FMI_CHECK_HIP(hipMemcpyAsync(ws.row_slot, slots.data(), n * 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipStreamSynchronize(s));
+  h->row_slot_host = slots;
   h->force_tiled = false;   // the head and the fast chain see n <= 16 rows in a full prefill too
   if (head_only) return tail_head(h, h->xl, n, s);
   return tail(h, h->xl, n, ws.row_slot, s);
@@ -901,8 +906,14 @@ int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frame
   for (int i = 0; i < n; ++i) FMI_CHECK(check_slot(h, slot_ids[i]));
   FMI_CHECK(sync_in(h, stream));
   hipStream_t s = h->stream;
-  FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, slot_ids, n * 4, hipMemcpyHostToDevice, s));
-  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  // the slot list of the frame graph: uploaded (and waited for: the source is the caller's memory) only when it
+  // changes -- a call that continues the previous one's slots does not drain the queue, so a streaming caller that cuts
+  // the frame loop into chunks keeps the GPU fed across its calls
+  if (h->row_slot_host != std::vector<int32_t>(slot_ids, slot_ids + n)) {
+    FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, slot_ids, n * 4, hipMemcpyHostToDevice, s));
+    FMI_CHECK_HIP(hipStreamSynchronize(s));
+    h->row_slot_host.assign(slot_ids, slot_ids + n);
+  }
   hipGraphExec_t exec = nullptr;
   if (h->use_graph && !h->trace) {
     auto it = h->graphs.find(n);
@@ -926,7 +937,27 @@ int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frame
     else FMI_CHECK(decode_frame(h, n, s));
   }
   FMI_CHECK_HIP(hipEventRecord(h->ev_t1, s));
-  return sync_out(h, stream);
+  // The caller's stream is NOT made to wait here.  A wait that stays pending on another hardware queue for the length
+  // of the frame loop costs every kernel dispatch of that loop (measured, tools/decode_chunk_probe.py: +0.3 ms per frame
+  // for the first ~30 frames of every call -- 4.81 -> 4.73 ms per frame for one 192-frame call, 5.10 -> 4.74 for calls
+  // of 32 frames).  The frames are ordered before every later call on this handle; a caller that reads them from its
+  // own stream first calls fmi_dualar_wait (stream order) or fmi_dualar_synchronize / poll_done / read (host).
+  FMI_CHECK_HIP(hipEventRecord(h->ev_out, s));
+  h->out_pending = true;
+  return FMI_OK;
+}
+
+int fmi_dualar_wait(fmi_dualar* h, void* stream) {
+  FMI_REQUIRE(h, "null handle");
+  if (h->out_pending) FMI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_out, 0));
+  return FMI_OK;
+}
+
+int fmi_dualar_synchronize(fmi_dualar* h) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  h->out_pending = false;
+  return FMI_OK;
 }
 
 int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_frame) {
@@ -1001,6 +1032,7 @@ int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int po
     FMI_CHECK(reserve_pages(h, slot, h->max_seq));
     FMI_CHECK(set_slot(h, slot, pos0, frame_index, h->max_seq, sp, false));
     FMI_CHECK_HIP(hipMemcpyAsync(h->st.cur + (int64_t)slot * ncb1, x_dev, ncb1 * 4, hipMemcpyDeviceToDevice, s));
+    h->row_slot_host.clear();
     FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
     FMI_CHECK_HIP(hipStreamSynchronize(s));
     if (prev_dev)
@@ -1033,6 +1065,7 @@ int fmi_dualar_forward_slow(fmi_dualar* h, int slot, const int32_t* x_dev, int S
     FMI_CHECK(reserve_pages(h, slot, h->max_seq));
     FMI_CHECK(set_slot(h, slot, pos0, 1, h->max_seq, sp, false));
     FMI_CHECK_HIP(hipMemcpyAsync(h->st.cur + (int64_t)slot * ncb1, x_dev, ncb1 * 4, hipMemcpyDeviceToDevice, s));
+    h->row_slot_host.clear();
     FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
     FMI_CHECK_HIP(hipStreamSynchronize(s));
     FMI_CHECK(decode_frame(h, 1, s, true));
@@ -1058,7 +1091,8 @@ int fmi_dualar_forward_fast(fmi_dualar* h, int slot, const void* hidden_in_dev, 
   FMI_CHECK(sync_in(h, stream));
   hipStream_t s = h->stream;
   FMI_CHECK_HIP(hipMemcpyAsync(h->xf, hidden_in_dev, (size_t)c.fast_dim * 2, hipMemcpyDeviceToDevice, s));
-  FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
+  h->row_slot_host.clear();
+    FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
   FMI_CHECK_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < c.n_fast_layer; ++i) FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, 1, pos, h->ws.row_slot, s));
   FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, 1,

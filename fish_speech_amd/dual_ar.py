@@ -495,8 +495,16 @@ class MiDualAR:
         check(self.lib.fmi_dualar_out_ptr(self._h, C.byref(p), C.byref(mf)))
         ncb1 = self.config.num_codebooks + 1
         full = _from_ptr(p.value, (self.max_batch_size, mf.value, ncb1), torch.int32, self.device)
-        torch.cuda.current_stream(self.device).synchronize()
+        check(self.lib.fmi_dualar_synchronize(self._h))   # decode() leaves the caller's stream unordered (fishmi.h)
         return full[:n_slots, :n_frames]
+
+    def synchronize(self):
+        """host wait for everything enqueued on this model's stream"""
+        check(self.lib.fmi_dualar_synchronize(self._h))
+
+    def wait_stream(self):
+        """order torch's current stream after the frames of the last decode() call (no host wait)"""
+        check(self.lib.fmi_dualar_wait(self._h, self._stream()))
 
     def release(self, slot: int):
         self._cached_prompt.pop(int(slot), None)

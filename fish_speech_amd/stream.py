@@ -21,6 +21,7 @@ stream holds the newest frame back until a later one exists.
 """
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass
 from typing import Iterator, List, Optional, Sequence
 
@@ -56,11 +57,12 @@ def chunk_schedule(total_frames: int, first_chunk_frames: int, chunk_frames: int
 def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Tensor], max_new_tokens: int,
                     first_chunk_frames: int = 8, chunk_frames: int = 32, seeds: Optional[Sequence[int]] = None,
                     stop_on_im_end: bool = True, temperature: float = 1.0, top_p: float = 0.9, top_k: int = 30,
-                    use_ras: bool = True) -> Iterator[StreamChunk]:
+                    use_ras: bool = True, timing: Optional[list] = None) -> Iterator[StreamChunk]:
     """Generate a batch of utterances and yield their audio chunk by chunk.
 
     Utterance i's audio is the concatenation over chunks of ``chunk.audio[i, :, :valid_frames[i]*frame_length]``
-    and equals ``codec.from_indices(generate_batch(...)[i][1:, T_i:-1])``."""
+    and equals ``codec.from_indices(generate_batch(...)[i][1:, T_i:-1])``.  ``timing``: a list that receives the host
+    wall time of every phase per chunk (tools/stream_latency.py --timing)."""
     cfg = model.config
     n = len(prompts)
     for p in prompts:
@@ -83,10 +85,13 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
     length = [None] * n                                # final frame count of an utterance once it ended
     try:
         for mark in chunk_schedule(total, first_chunk_frames + 1, chunk_frames):
+            tm = [time.perf_counter()] if timing is not None else None
             if mark > generated:
                 model.decode(slots, mark - generated)
                 generated = mark
+            if tm: tm.append(time.perf_counter())
             done = model.poll_done(slots) if stop_on_im_end else [0] * n
+            if tm: tm.append(time.perf_counter())
             for i in slots:
                 if length[i] is None and (done[i] or generated >= mn[i]):
                     length[i] = model.read(i)[0].shape[0] if done[i] else mn[i]
@@ -97,7 +102,12 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
             if t1 > emitted:
                 frames = model.frames_device(n, t1)                       # (B, t1, 1+ncb) int32
                 codes = frames[:, :, 1:].permute(0, 2, 1).to(torch.int64).contiguous()
+                if tm: tm.append(time.perf_counter())
                 audio = codec.from_indices_tail(codes, emitted, stream_id=stream_id)
+                if tm:
+                    tm.append(time.perf_counter())
+                    timing.append(dict(t1=t1, decode_call=tm[1] - tm[0], poll=tm[2] - tm[1], frames=tm[3] - tm[2],
+                                       codec_call=tm[4] - tm[3]))
                 yield StreamChunk(emitted, t1, audio, codes[:, :, emitted:t1],
                                   [max(0, min(v, t1) - emitted) for v in voiced], finished)
                 emitted = t1

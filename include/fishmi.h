@@ -111,8 +111,15 @@ int fmi_dualar_prefill_resume(fmi_dualar* h, int n, const int32_t* slot_ids, con
 
 /* Advance the given slots by n_frames frames (one hipGraph replay per frame; no host sync
  * inside).  Replaces decode_n_tokens (inference.py:184-238) for a batch. A slot that emitted
- * <|im_end|> or exhausted its reservation stops advancing. */
+ * <|im_end|> or exhausted its reservation stops advancing.
+ * Ordering: the frames run after everything already enqueued on `stream` and before every later call on this handle;
+ * `stream` itself is NOT made to wait for them (a cross-queue wait that stays pending for the length of the frame loop
+ * slows every dispatch of the loop: +0.3 ms per frame measured).  A caller that consumes the frames on its own stream
+ * (fmi_dualar_out_ptr) calls fmi_dualar_wait(h, stream) first; fmi_dualar_poll_done / _read / _synchronize wait on the
+ * host. */
 int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frames, void* stream);
+int fmi_dualar_wait(fmi_dualar* h, void* stream);   /* order `stream` after the frames of the last decode call */
+int fmi_dualar_synchronize(fmi_dualar* h);          /* host wait for everything enqueued on this handle */
 
 /* Copy out what a slot generated so far: frames (n_frames, 1+num_codebooks) int32 into
  * out_host (capacity max_frames); *n_frames_out = count, *done_out = 1 if the slot ended

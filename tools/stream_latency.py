@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--first", type=int, default=8)
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--runs", type=int, default=9)
+    ap.add_argument("--timing", action="store_true", help="host wall time per phase and chunk of the last run")
     args = ap.parse_args()
     device = torch.device("cuda:0")
     from fish_speech_amd.dac import DacConfig, MiDAC
@@ -41,14 +42,20 @@ def main():
     seeds = [4242 + i for i in range(bench.BATCH)]
     n_new = bench.N_FRAMES + 1   # the last generated frame is never voiced (inference.py:708)
 
+    timing = []
+
     def one_run():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         first, n_samples, marks = None, 0, []
+        timing.clear()
         for ch in generate_stream(model=model, codec=codec, prompts=prompts, max_new_tokens=n_new,
                                   first_chunk_frames=args.first, chunk_frames=args.chunk, seeds=seeds,
-                                  temperature=0.7, top_p=0.7, top_k=30):
+                                  temperature=0.7, top_p=0.7, top_k=30, timing=timing if args.timing else None):
+            ts = time.perf_counter()
             torch.cuda.synchronize()
+            if timing:
+                timing[-1]["consumer_sync"] = time.perf_counter() - ts
             if first is None:
                 first = time.perf_counter() - t0
             n_samples += ch.audio.shape[-1]
@@ -69,6 +76,8 @@ def main():
     offline = time.perf_counter() - t0
     audio_s = bench.BATCH * n_samples / bench.SAMPLE_RATE
     print(f"chunks end at frames {marks}")
+    for t in timing:
+        print("  chunk to frame %3d: " % t["t1"] + "  ".join(f"{k} {v * 1e3:7.2f} ms" for k, v in t.items() if k != "t1"))
     print(f"first audio ({args.first} frames = {args.first * bench.FRAME_LEN / bench.SAMPLE_RATE * 1e3:.0f} ms of audio "
           f"x {bench.BATCH} utterances): p50 {statistics.median(firsts):.1f} ms  min {min(firsts):.1f}  max {max(firsts):.1f}  "
           f"({args.runs} runs)")
