@@ -41,14 +41,21 @@ class StreamChunk:
     finished: List[bool]    # per utterance: generation has ended
 
 
-def chunk_schedule(total_frames: int, first_chunk_frames: int, chunk_frames: int) -> List[int]:
-    """Frame counts at which audio is emitted: first_chunk_frames, then every chunk_frames."""
+def chunk_schedule(total_frames: int, first_chunk_frames: int, chunk_frames: int, growth: float = 1.0,
+                   max_chunk_frames: int = 256) -> List[int]:
+    """Frame counts at which audio is emitted: first_chunk_frames, then every chunk_frames.  growth > 1 lengthens every
+    later chunk by that factor (up to max_chunk_frames): frames are generated several times faster than they play, so
+    the playback buffer grows and later chunks can be longer -- fewer incremental codec decodes, each of which re-reads
+    the decoder's left context and runs latency-bound small launches."""
     if first_chunk_frames < 1 or chunk_frames < 1:
         raise ValueError("chunk sizes must be >= 1")
-    marks, t = [], min(first_chunk_frames, total_frames)
+    if growth < 1.0 or max_chunk_frames < 1:
+        raise ValueError("growth must be >= 1 and max_chunk_frames >= 1")
+    marks, t, step = [], min(first_chunk_frames, total_frames), float(min(chunk_frames, max_chunk_frames))
     while t < total_frames:
         marks.append(t)
-        t += chunk_frames
+        t += max(1, int(step))
+        step = min(step * growth, float(max_chunk_frames))
     marks.append(total_frames)
     return marks
 
@@ -57,7 +64,8 @@ def chunk_schedule(total_frames: int, first_chunk_frames: int, chunk_frames: int
 def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Tensor], max_new_tokens: int,
                     first_chunk_frames: int = 8, chunk_frames: int = 32, seeds: Optional[Sequence[int]] = None,
                     stop_on_im_end: bool = True, temperature: float = 1.0, top_p: float = 0.9, top_k: int = 30,
-                    use_ras: bool = True, timing: Optional[list] = None) -> Iterator[StreamChunk]:
+                    use_ras: bool = True, timing: Optional[list] = None, chunk_growth: float = 1.0,
+                    max_chunk_frames: int = 256) -> Iterator[StreamChunk]:
     """Generate a batch of utterances and yield their audio chunk by chunk.
 
     Utterance i's audio is the concatenation over chunks of ``chunk.audio[i, :, :valid_frames[i]*frame_length]``
@@ -84,7 +92,7 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
     stream_id = codec.new_stream_id()                  # the codec keeps its quantizer-side state between our calls
     length = [None] * n                                # final frame count of an utterance once it ended
     try:
-        for mark in chunk_schedule(total, first_chunk_frames + 1, chunk_frames):
+        for mark in chunk_schedule(total, first_chunk_frames + 1, chunk_frames, chunk_growth, max_chunk_frames):
             tm = [time.perf_counter()] if timing is not None else None
             if mark > generated:
                 model.decode(slots, mark - generated)

@@ -120,10 +120,16 @@ def test_chunk_schedule():
         chunk_schedule(10, 0, 4)
     with pytest.raises(ValueError):
         chunk_schedule(10, 4, 0)
+    # growing chunks: 32, 64, 128, capped
+    assert chunk_schedule(215, 8, 32, growth=2.0) == [8, 40, 104, 215]
+    assert chunk_schedule(600, 8, 32, growth=2.0, max_chunk_frames=100) == [8, 40, 104, 204, 304, 404, 504, 600]
+    assert chunk_schedule(50, 8, 4, growth=1.5) == [8, 12, 18, 27, 40, 50]
+    with pytest.raises(ValueError):
+        chunk_schedule(10, 4, 4, growth=0.5)
 
 
-@pytest.mark.parametrize("first,chunk", [(8, 32), (1, 1), (3, 5), (64, 64)])
-def test_generate_stream_emits_exactly_the_offline_frames(first, chunk):
+@pytest.mark.parametrize("first,chunk,growth", [(8, 32, 1.0), (1, 1, 1.0), (3, 5, 1.0), (64, 64, 1.0), (2, 2, 2.0)])
+def test_generate_stream_emits_exactly_the_offline_frames(first, chunk, growth):
     """Ragged batch (utterances end at 17, 30, 6 and -- cut by max_new_tokens -- 20 frames): per utterance the
     concatenation of the valid parts of all chunks is from_indices over codes[1:, T:-1]; the newest frame of a live
     utterance is held back; chunks continue one codec stream (t0 of a call = T of the previous one, same id); every
@@ -137,7 +143,7 @@ def test_generate_stream_emits_exactly_the_offline_frames(first, chunk):
     codes = [[] for _ in seeds]
     last_t1 = 0
     for ch in generate_stream(model=model, codec=codec, prompts=prompts, max_new_tokens=max_new,
-                              first_chunk_frames=first, chunk_frames=chunk, seeds=seeds):
+                              first_chunk_frames=first, chunk_frames=chunk, seeds=seeds, chunk_growth=growth):
         assert ch.t0 == last_t1 and ch.t1 > ch.t0
         last_t1 = ch.t1
         for i, v in enumerate(ch.valid_frames):

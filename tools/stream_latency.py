@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--first", type=int, default=8)
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--runs", type=int, default=9)
+    ap.add_argument("--growth", type=float, default=1.0, help="every later chunk is this much longer (chunk_schedule)")
     ap.add_argument("--timing", action="store_true", help="host wall time per phase and chunk of the last run")
     args = ap.parse_args()
     device = torch.device("cuda:0")
@@ -51,7 +52,8 @@ def main():
         timing.clear()
         for ch in generate_stream(model=model, codec=codec, prompts=prompts, max_new_tokens=n_new,
                                   first_chunk_frames=args.first, chunk_frames=args.chunk, seeds=seeds,
-                                  temperature=0.7, top_p=0.7, top_k=30, timing=timing if args.timing else None):
+                                  temperature=0.7, top_p=0.7, top_k=30, timing=timing if args.timing else None,
+                                  chunk_growth=args.growth):
             ts = time.perf_counter()
             torch.cuda.synchronize()
             if timing:
