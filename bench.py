@@ -306,13 +306,13 @@ def run_config5(model, codec, cfg, device, runs=5, first=8, chunk=32):
     prompts = make_prompts(cfg, BATCH, 1000)
     seeds = [4242 + i for i in range(BATCH)]
 
-    def once():
+    def once(growth=1.0):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         first_t, n = None, 0
         for ch in generate_stream(model=model, codec=codec, prompts=prompts, max_new_tokens=N_FRAMES + 1,
                                   first_chunk_frames=first, chunk_frames=chunk, seeds=seeds, temperature=0.7,
-                                  top_p=0.7, top_k=30):
+                                  top_p=0.7, top_k=30, chunk_growth=growth):
             torch.cuda.synchronize()
             if first_t is None:
                 first_t = time.perf_counter() - t0
@@ -322,9 +322,12 @@ def run_config5(model, codec, cfg, device, runs=5, first=8, chunk=32):
     once()
     rs = [once() for _ in range(runs)]
     tot = statistics.median(r[1] for r in rs)
+    once(2.0)
+    grow = statistics.median(once(2.0)[1] for _ in range(3))
     return {"workload": f"configs[4]: streaming, batch=8, first chunk {first} frames then every {chunk}",
             "first_audio_ms_p50": round(statistics.median(r[0] for r in rs) * 1e3, 2),
-            "stream_audio_sec_per_s": round(BATCH * rs[0][2] / SAMPLE_RATE / tot, 2)}
+            "stream_audio_sec_per_s": round(BATCH * rs[0][2] / SAMPLE_RATE / tot, 2),
+            "stream_audio_sec_per_s_growing_chunks": round(BATCH * rs[0][2] / SAMPLE_RATE / grow, 2)}
 
 
 def respawn_under_torchrun(n):

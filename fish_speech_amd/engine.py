@@ -57,6 +57,8 @@ class TTSRequest:
     top_k: int = 30
     first_chunk_frames: int = 8
     chunk_frames: int = 32
+    chunk_growth: float = 2.0      # later chunks 32, 64, 128 ... frames: generation outruns playback, fewer codec calls
+    max_chunk_frames: int = 256
 
 
 class StreamingTTSEngine:
@@ -90,7 +92,8 @@ class StreamingTTSEngine:
                 with torch.autocast("cuda", dtype=self.precision, enabled=self.precision is not None):
                     for ch in generate_stream(model=model, codec=codec, prompts=[prompt],
                                               max_new_tokens=req.max_new_tokens, first_chunk_frames=req.first_chunk_frames,
-                                              chunk_frames=req.chunk_frames, seeds=seeds, temperature=req.temperature,
+                                              chunk_frames=req.chunk_frames, chunk_growth=req.chunk_growth,
+                                              max_chunk_frames=req.max_chunk_frames, seeds=seeds, temperature=req.temperature,
                                               top_p=req.top_p, top_k=req.top_k):
                         n = ch.valid_frames[0]
                         if n <= 0:
