@@ -733,72 +733,87 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
 // column-wise norms ([B][C][L]: statistics over C for each (b, t))
 // =====================================================================================
 
-// block (32 columns, 8 channel groups)
-__global__ __launch_bounds__(256) void rmsnorm_cols_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float eps, float* __restrict__ out, int C, int L) {
-  __shared__ float part[8][32];
+// block (32 columns, NG channel groups): thread (column, group) walks the channels group, group + NG, ...; the group
+// partials meet in LDS and are summed in group order.  32 groups (1024 threads): a streaming chunk of 32 frames is one
+// work-group per utterance, so the length of the per-thread channel walk IS the kernel's duration (8 groups: 40-48 us
+// for a megabyte of data, 17 launches per decode).
+constexpr int NORM_NG = 32;
+
+__global__ __launch_bounds__(32 * NORM_NG) void rmsnorm_cols_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    float eps, float* __restrict__ out, int C, int L) {
+  __shared__ float part[NORM_NG][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t = blockIdx.x * 32 + tx, b = blockIdx.y;
   const float* xb = x + (int64_t)b * C * L;
   float ss = 0.f;
-  if (t < L)
-    for (int c = ty; c < C; c += 8) {
+  if (t < L) {
+#pragma unroll 4
+    for (int c = ty; c < C; c += NORM_NG) {
       const float v = xb[(int64_t)c * L + t];
       ss += v * v;
     }
+  }
   part[ty][tx] = ss;
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) tot += part[i][tx];
+  for (int i = 0; i < NORM_NG; ++i) tot += part[i][tx];
   const float rstd = rsqrtf(tot / (float)C + eps);
-  if (t < L)
-    for (int c = ty; c < C; c += 8) out[(int64_t)b * C * L + (int64_t)c * L + t] = xb[(int64_t)c * L + t] * rstd * w[c];
+  if (t < L) {
+#pragma unroll 4
+    for (int c = ty; c < C; c += NORM_NG) out[(int64_t)b * C * L + (int64_t)c * L + t] = xb[(int64_t)c * L + t] * rstd * w[c];
+  }
 }
 
 int launch_rmsnorm_cols(const float* x, const float* w, float eps, float* out, int B, int C, int L, hipStream_t s) {
-  hipLaunchKernelGGL(rmsnorm_cols_kernel, dim3(cdiv(L, 32), B), dim3(256), 0, s, x, w, eps, out, C, L);
+  hipLaunchKernelGGL(rmsnorm_cols_kernel, dim3(cdiv(L, 32), B), dim3(32 * NORM_NG), 0, s, x, w, eps, out, C, L);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
 
-__global__ __launch_bounds__(256) void layernorm_cols_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float eps,
-                                                             float* __restrict__ out, int C, int L) {
-  __shared__ float part[8][32];
+__global__ __launch_bounds__(32 * NORM_NG) void layernorm_cols_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias, float eps,
+                                                                      float* __restrict__ out, int C, int L) {
+  __shared__ float part[NORM_NG][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t = blockIdx.x * 32 + tx, b = blockIdx.y;
   const float* xb = x + (int64_t)b * C * L;
   float sm = 0.f;
-  if (t < L)
-    for (int c = ty; c < C; c += 8) sm += xb[(int64_t)c * L + t];
+  if (t < L) {
+#pragma unroll 4
+    for (int c = ty; c < C; c += NORM_NG) sm += xb[(int64_t)c * L + t];
+  }
   part[ty][tx] = sm;
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) tot += part[i][tx];
+  for (int i = 0; i < NORM_NG; ++i) tot += part[i][tx];
   const float mean = tot / (float)C;
   __syncthreads();
   float sv = 0.f;
-  if (t < L)
-    for (int c = ty; c < C; c += 8) {
+  if (t < L) {
+#pragma unroll 4
+    for (int c = ty; c < C; c += NORM_NG) {
       const float d = xb[(int64_t)c * L + t] - mean;
       sv += d * d;
     }
+  }
   part[ty][tx] = sv;
   __syncthreads();
   tot = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) tot += part[i][tx];
+  for (int i = 0; i < NORM_NG; ++i) tot += part[i][tx];
   const float rstd = rsqrtf(tot / (float)C + eps);
-  if (t < L)
-    for (int c = ty; c < C; c += 8)
+  if (t < L) {
+#pragma unroll 4
+    for (int c = ty; c < C; c += NORM_NG)
       out[(int64_t)b * C * L + (int64_t)c * L + t] = (xb[(int64_t)c * L + t] - mean) * rstd * w[c] + bias[c];
+  }
 }
 
 int launch_layernorm_cols(const float* x, const float* w, const float* b, float eps, float* out, int B, int C, int L,
                           hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_cols_kernel, dim3(cdiv(L, 32), B), dim3(256), 0, s, x, w, b, eps, out, C, L);
+  hipLaunchKernelGGL(layernorm_cols_kernel, dim3(cdiv(L, 32), B), dim3(32 * NORM_NG), 0, s, x, w, b, eps, out, C, L);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
