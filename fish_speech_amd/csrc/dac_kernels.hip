@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
 
   const int qw = wave * NT * 32;
   const int nblk = (wx + 63) >> 6;
-  constexpr int SU = G >= 4 ? 4 : 2;
+  constexpr int SU = G >= 8 ? 8 : (G >= 4 ? 4 : 2);
   const char* a_lane = Ws + li * 32 + (((lk ^ (li >> 3)) & 1) << 4);
   auto fetch_w = [&](int cg0, int t0, int nt) {   // (tap, group, plane) rows of taps [t0, t0 + nt), MT KiB each
     for (int p = wave; p < nt * G * NP * MT; p += 4) {
@@ -659,7 +659,11 @@ static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span
     if (small)
       for (int m : {4, 3, 2, 1})
         if (ct % m == 0 && (col_tiles * (ct / m) >= 256 || m == 1)) { MT = m; break; }
-    const int want = env_g ? env_g : (small ? 4 : 2);
+    static const int env_gs = []() { const char* e = getenv("FMI_CONV_K1G_SMALL"); return e ? atoi(e) : 4; }();
+    // few column tiles (the codec transformer, a streaming chunk): every work-group walks the whole reduction as a chain
+    // of load -> split -> barrier -> MFMA steps with little else to overlap it; 64-channel steps halve the chain
+    static const int env_few = []() { const char* e = getenv("FMI_CONV_K1_FEWCOLS"); return e ? atoi(e) : 16; }();
+    const int want = env_g ? env_g : (small ? env_gs : (col_tiles <= env_few ? 4 : 2));
     const int nt = small || MT == 4 ? 1 : MT == 3 ? ((env_nt == 1 || (NP == 2 && env_nt != 2)) ? 1 : 2) : MT == 2 ? 2 : 4;
     for (int g : {8, 4, 2})   // both tiles of a step within 128 KiB of LDS
       if (g <= want && cgs % g == 0 && (size_t)g * NP * (4 * nt * 32 + MT * 32) * 32 <= 128 * 1024) { kg = g; break; }

@@ -1,6 +1,6 @@
 """One incremental codec decode (frames [T0, T1) of 8 utterances) repeated: run under rocprofv3 --kernel-trace.
 CACHED=1: the quantizer-side state of frames [0, T0) is kept (stream_id), as generate_stream does."""
-import os, sys
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import synthetic_codec_state
@@ -19,8 +19,13 @@ for _ in range(int(os.environ.get("N", 5))):
         sid = codec.new_stream_id()
         codec.from_indices_tail(codes[:, :, :T0].clone(), 0, stream_id=sid)
         torch.cuda.synchronize()
-        print("MARK", flush=True)
-        codec.from_indices_tail(codes.clone(), T0, stream_id=sid)
+        time.sleep(0.1)          # an idle gap: tools/rocpd_clusters.py splits the trace into bursts there
+        c = codes.clone()
+        torch.cuda.synchronize()
+        time.sleep(0.1)
+        codec.from_indices_tail(c, T0, stream_id=sid)
+        torch.cuda.synchronize()
+        time.sleep(0.1)
     else:
         codec.from_indices_tail(codes.clone(), T0)
 torch.cuda.synchronize()
