@@ -413,6 +413,38 @@ int run_res_unit(fmi_dac* h, const ResUnit& r, float* x, float* y, int B, int L)
   return run_conv(h, r.c1, y, x, B, L, nullptr, r.a2, x, nullptr, ACT_NONE);
 }
 
+// The codec transformer on operand planes (fp16 split arithmetic only): column norm / attention / SiLU-mul hand fp16
+// hi/lo planes to linear_planes_kernel, which fetches both MFMA operands from L2 without any staging.
+bool tf_on_planes(const fmi_dac* h, const Tf& t) {
+  static const bool off = []() { const char* e = getenv("FMI_DAC_TF_PLANES"); return e && atoi(e) == 0; }();
+  if (off || h->cur_planes != 2 || t.layers.empty() || h->head_dim != 64 || t.window > 128) return false;
+  if (t.dim % 16 || t.ffn % 16) return false;
+  for (const TfLayer& L : t.layers)
+    for (const Conv* c : {&L.wqkv, &L.wo, &L.w13, &L.w2})
+      if (!c->w.wb || c->w.taps != 1 || c->w.phases != 1 || c->w.cin_pad16 != c->w.cin) return false;
+  return true;
+}
+
+// one layer on columns [q_lo, T) of qkv_hist (row stride ld; q_lo = 0, ld = T offline); x, nbp, qkv, ab, actp are compact
+// over the n = T - q_lo new columns
+int tf_layer_planes(fmi_dac* h, const Tf& t, const TfLayer& L, float* x, bf16_t* nbp, float* qkv, float* qkv_hist, int ld,
+                    float* ab, bf16_t* actp, int B, int T, int q_lo) {
+  const int C = t.dim, F = t.ffn, n = T - q_lo;
+  hipStream_t s = h->stream;
+  FMI_CHECK(launch_rmsnorm_cols_planes(x, L.attn_norm, h->eps, nbp, B, C, n, s));
+  FMI_CHECK(launch_linear_planes(L.wqkv.w, nbp, qkv, nullptr, nullptr, ACT_NONE, B, n, s));
+  FMI_CHECK(launch_rope_cols(qkv, h->rope + (int64_t)q_lo * h->head_dim, B, C, n, h->head_dim, s));
+  if (qkv_hist != qkv)
+    FMI_CHECK_HIP(hipMemcpy2DAsync(qkv_hist + q_lo, (size_t)ld * 4, qkv, (size_t)n * 4, (size_t)n * 4, (size_t)B * 3 * C,
+                                   hipMemcpyDeviceToDevice, s));
+  FMI_CHECK(launch_window_attn(qkv_hist, nullptr, B, C, T, h->head_dim, t.window, s, ld, q_lo, nbp));
+  FMI_CHECK(launch_linear_planes(L.wo.w, nbp, x, x, L.g_attn, ACT_NONE, B, n, s));
+  FMI_CHECK(launch_rmsnorm_cols_planes(x, L.ffn_norm, h->eps, nbp, B, C, n, s));
+  FMI_CHECK(launch_linear_planes(L.w13.w, nbp, ab, nullptr, nullptr, ACT_NONE, B, n, s));
+  FMI_CHECK(launch_silu_mul_planes(ab, actp, B, F, n, s));
+  return launch_linear_planes(L.w2.w, actp, x, x, L.g_ffn, ACT_NONE, B, n, s);
+}
+
 // WindowLimitedTransformer on x [B][dim][T]; result written to out (may alias x)
 int run_transformer(fmi_dac* h, const Tf& t, float* x, float* out, int B, int T) {
   const int C = t.dim, F = t.ffn;
@@ -423,6 +455,11 @@ int run_transformer(fmi_dac* h, const Tf& t, float* x, float* out, int B, int T)
   FMI_CHECK(ensure_buf(h, 5, (int64_t)B * F * T));       // activation
   float *nb = h->buf[2].p, *qkv = h->buf[3].p, *ab = h->buf[4].p, *act = h->buf[5].p;
   hipStream_t s = h->stream;
+  if (tf_on_planes(h, t)) {
+    for (const TfLayer& L : t.layers)
+      FMI_CHECK(tf_layer_planes(h, t, L, x, (bf16_t*)nb, qkv, qkv, T, ab, (bf16_t*)act, B, T, 0));
+    return launch_rmsnorm_cols(x, t.norm, h->eps, out, B, C, T, s);
+  }
   for (const TfLayer& L : t.layers) {
     FMI_CHECK(launch_rmsnorm_cols(x, L.attn_norm, h->eps, nb, B, C, T, s));
     FMI_CHECK(run_conv(h, L.wqkv, nb, qkv, B, T, nullptr, nullptr, nullptr, nullptr, ACT_NONE));
@@ -619,9 +656,14 @@ int run_quantizer_decode_inc(fmi_dac* h, int64_t* indices_dev, int B, int T, int
   FMI_CHECK(launch_lut_decode(indices_dev, h->lut, h->lut_off, c.n_codebooks, c.semantic_codebook_size, c.codebook_size,
                               Y, B, L0, T, s));
   FMI_CHECK(copy_cols(h, X, n, Y + t0, T, n, (int64_t)B * C));
+  const bool on_planes = tf_on_planes(h, tf);
   for (size_t li = 0; li < tf.layers.size(); ++li) {
     const TfLayer& L = tf.layers[li];
     float* hist = h->st.qkv[li];
+    if (on_planes) {
+      FMI_CHECK(tf_layer_planes(h, tf, L, X, (bf16_t*)nb, qkv, hist, cap, ab, (bf16_t*)act, B, T, t0));
+      continue;
+    }
     FMI_CHECK(launch_rmsnorm_cols(X, L.attn_norm, h->eps, nb, B, C, n, s));
     FMI_CHECK(run_conv(h, L.wqkv, nb, qkv, B, n, nullptr, nullptr, nullptr, nullptr, ACT_NONE));
     FMI_CHECK(launch_rope_cols(qkv, h->rope + (int64_t)t0 * h->head_dim, B, C, n, h->head_dim, s));

@@ -80,7 +80,15 @@ int launch_rope_cols(float* qkv /*[B][3C][L]*/, const bf16_t* table /*[L][hd/2][
                      hipStream_t s);
 // ld: row stride of qkv (0 = L); only queries q_lo..L-1 are computed, out is the compact [B][C][L - q_lo]
 int launch_window_attn(const float* qkv /*[B][3C][ld]*/, float* out /*[B][C][L - q_lo]*/, int B, int C, int L, int hd,
-                       int window, hipStream_t s, int ld = 0, int q_lo = 0);
+                       int window, hipStream_t s, int ld = 0, int q_lo = 0, bf16_t* outp = nullptr);
+// operand-plane producers / consumer of the codec transformer (fp16 split arithmetic, C % 16 == 0):
+//   planes [B][C/16][2][L][16] fp16 (hi, lo * 2^11), the layout of ConvArgs::xp
+int launch_rmsnorm_cols_planes(const float* x, const float* w, float eps, bf16_t* outp, int B, int C, int L, hipStream_t s);
+int launch_silu_mul_planes(const float* ab /*[B][2F][L]*/, bf16_t* outp /*planes of [B][F][L]*/, int B, int F, int L, hipStream_t s);
+// out = res + gamma * act(W x + bias) for a k = 1 layer, x given as operand planes; every wave fetches both MFMA operands
+// straight from L2 (no LDS staging): bit-identical to launch_conv with planes = 2 on the fp32 tensor
+int launch_linear_planes(const ConvW& w, const bf16_t* xp, float* out, const float* res, const float* gamma, int act,
+                         int B, int L, hipStream_t s);
 int launch_lut_decode(const int64_t* idx /*[B][1+n][T]*/, const float* tables, const int* table_rows_off,
                       int n_books, int sem_size, int cb_size, float* out /*[B][C][T]*/, int B, int C, int T,
                       hipStream_t s);

@@ -687,6 +687,121 @@ static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span
 #undef FMI_CONVB
 }
 
+// =====================================================================================
+// k = 1 layer on ready operand planes, every wave on its own (the codec transformer's linears)
+// =====================================================================================
+// The conv kernel above stages the input tile of EVERY 32..128-row work-group through LDS (load, fp16 split, barrier):
+// for a linear over a few hundred columns that staging is the whole cost (a 1024 x 1024 x 256 GEMM took 55 us, a
+// 1024 x 3072 one 150 us).  Here the producer (column norm, SiLU-mul, attention) has already written the activations as
+// fp16 hi/lo operand planes [B][cin/16][2][L][16] -- the layout of ConvArgs::xp -- and the weights are operand planes
+// too (ConvW::wb), so a wave fetches both MFMA operands straight from L2 with one 16-byte load per lane and plane, no
+// LDS, no barrier; four independent waves per work-group, each a (32 MT rows x 32 columns) tile over the whole
+// reduction.  Same products in the same order per output element as conv_mfma_bf16_kernel<.., NP = 2>.
+template <int MT>
+__global__ __launch_bounds__(256) void linear_planes_kernel(ConvW w, const bf16_t* __restrict__ xp, float* __restrict__ out,
+                                                           const float* __restrict__ res, const float* __restrict__ gamma,
+                                                           int act, int L) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rt = blockIdx.y * 4 + wave;
+  const int co0 = rt * (32 * MT);
+  if (co0 >= w.cout_pad) return;
+  const int q = blockIdx.x * 32 + li, b = blockIdx.z;
+  const bool live = q < L;
+  const int cgs = w.cin_pad16 >> 4;
+  // A: slot 1 / 2 of group g, row co: 16 halfs at ((g * 3 + slot) * cout_pad + co) * 16, halves swapped on rows with bit 3
+  const char* wa = reinterpret_cast<const char*>(w.wb) + ((int64_t)(cgs > 0 ? 1 : 0) * w.cout_pad + co0 + li) * 32 +
+                   (((lk ^ (li >> 3)) & 1) << 4);
+  const int64_t wa_group = (int64_t)3 * w.cout_pad * 32, wa_plane = (int64_t)w.cout_pad * 32;
+  // B: plane pl of group g, column q: 16 halfs at (((b * cgs + g) * 2 + pl) * L + q) * 16
+  const char* xb = reinterpret_cast<const char*>(xp) + (((int64_t)b * cgs * 2) * L + (live ? q : 0)) * 32 + lk * 16;
+  const int64_t xb_plane = (int64_t)L * 32, xb_group = 2 * xb_plane;
+
+  f32x16 acc[MT], acx[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = acx[i][r] = 0.f;
+
+  // a ring of R channel groups in registers: the operands of group g + R are requested right after group g's products
+  // are issued, so R - 1 groups of matrix work (and their load latency) overlap every L2 round trip
+  constexpr int R = MT == 1 ? 8 : 4;
+  f16x8 a0[R][MT], a1[R][MT], b0[R], b1[R];
+  auto fetch = [&](int g, int r) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      a0[r][i] = *reinterpret_cast<const f16x8*>(wa + g * wa_group + i * 1024);
+      a1[r][i] = *reinterpret_cast<const f16x8*>(wa + g * wa_group + wa_plane + i * 1024);
+    }
+    b0[r] = *reinterpret_cast<const f16x8*>(xb + g * xb_group);
+    b1[r] = *reinterpret_cast<const f16x8*>(xb + g * xb_group + xb_plane);
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (r < cgs) fetch(r, r);
+  for (int g0 = 0; g0 < cgs; g0 += R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int g = g0 + r;
+      if (g < cgs) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[r][i], b1[r], acx[i], 0, 0, 0);
+          acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[r][i], b0[r], acx[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[r][i], b0[r], acc[i], 0, 0, 0);
+        }
+        if (g + R < cgs) fetch(g + R, r);
+      }
+    }
+  }
+
+  // epilogue as conv_mfma_bf16_kernel: out = res + gamma * act(acc + bias)
+  if (!live) return;
+  const int co_last = w.cout - 1;
+  float* ob = out + (int64_t)b * w.cout * L;
+  const float* rb = res ? res + (int64_t)b * w.cout * L : nullptr;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row0 = co0 + i * 32 + 4 * lk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = row0 + 8 * (r >> 2) + (r & 3);
+      if (co > co_last) continue;
+      float v = (acc[i][r] + acx[i][r] * (1.0f / F16_LO_SCALE)) + (w.bias ? w.bias[co] : 0.f);
+      if (act == ACT_GELU) v = gelu_f(v);
+      v = v * (gamma ? gamma[co] : 1.f) + (rb ? rb[(int64_t)co * L + q] : 0.f);
+      ob[(int64_t)co * L + q] = v;
+    }
+  }
+}
+
+int launch_linear_planes(const ConvW& w, const bf16_t* xp, float* out, const float* res, const float* gamma, int act,
+                         int B, int L, hipStream_t s) {
+  FMI_REQUIRE(w.wb && w.taps == 1 && w.phases == 1 && w.cin % 16 == 0 && w.cin_pad16 == w.cin && w.cout_pad % 32 == 0,
+              "linear_planes: layer is not a plain k = 1 layer with operand planes");
+  const int ct = w.cout_pad / 32;
+  // 64-row wave tiles only when that still leaves every SIMD several waves
+  static const int env_mt = []() { const char* e = getenv("FMI_LINP_MT"); return e ? atoi(e) : 0; }();
+  const bool mt2 = env_mt ? env_mt == 2 : (ct % 2 == 0 && (int64_t)cdiv(L, 32) * (ct / 2) * B >= 4096);
+  if (mt2 && ct % 2 == 0) {
+    dim3 grid(cdiv(L, 32), cdiv(ct / 2, 4), B);
+    hipLaunchKernelGGL(linear_planes_kernel<2>, grid, dim3(256), 0, s, w, xp, out, res, gamma, act, L);
+  } else {
+    dim3 grid(cdiv(L, 32), cdiv(ct, 4), B);
+    hipLaunchKernelGGL(linear_planes_kernel<1>, grid, dim3(256), 0, s, w, xp, out, res, gamma, act, L);
+  }
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// one value as its two fp16 operand-plane halves
+__device__ inline void split1_f16(float x, uint16_t& h, uint16_t& l) {
+  uint32_t hh, ll;
+  split2_f16_pk(x, 0.f, hh, ll);
+  h = (uint16_t)hh;
+  l = (uint16_t)ll;
+}
+
 template <int MT, int NT, int G>
 static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
   const ConvW& w = a.w;
@@ -775,6 +890,51 @@ int launch_rmsnorm_cols(const float* x, const float* w, float eps, float* out, i
   return FMI_OK;
 }
 
+// the same statistics; the normalised tensor leaves as fp16 hi/lo operand planes [B][C/16][2][L][16] (C % 16 == 0):
+// a thread writes four channels (8 bytes) of a column per plane
+__global__ __launch_bounds__(32 * NORM_NG) void rmsnorm_cols_planes_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                           float eps, bf16_t* __restrict__ outp, int C, int L) {
+  __shared__ float part[NORM_NG][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + tx, b = blockIdx.y;
+  const float* xb = x + (int64_t)b * C * L;
+  float ss = 0.f;
+  if (t < L) {
+#pragma unroll 4
+    for (int c = ty; c < C; c += NORM_NG) {
+      const float v = xb[(int64_t)c * L + t];
+      ss += v * v;
+    }
+  }
+  part[ty][tx] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_NG; ++i) tot += part[i][tx];
+  const float rstd = rsqrtf(tot / (float)C + eps);
+  if (t >= L) return;
+  char* ob = reinterpret_cast<char*>(outp) + ((int64_t)b * (C >> 4) * 2) * L * 32;
+  for (int c4 = ty; c4 < (C >> 2); c4 += NORM_NG) {
+    const int c = c4 * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = xb[(int64_t)(c + e) * L + t] * rstd * w[c + e];
+    uint32_t h0, l0, h1, l1;
+    split2_f16_pk(v[0], v[1], h0, l0);
+    split2_f16_pk(v[2], v[3], h1, l1);
+    char* dst = ob + (((int64_t)(c >> 4) * 2) * L + t) * 32 + (c & 15) * 2;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + (int64_t)L * 32) = make_uint2(l0, l1);
+  }
+}
+
+int launch_rmsnorm_cols_planes(const float* x, const float* w, float eps, bf16_t* outp, int B, int C, int L, hipStream_t s) {
+  FMI_REQUIRE(C % 16 == 0, "rmsnorm planes: C %% 16");
+  hipLaunchKernelGGL(rmsnorm_cols_planes_kernel, dim3(cdiv(L, 32), B), dim3(32 * NORM_NG), 0, s, x, w, eps, outp, C, L);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
 __global__ __launch_bounds__(32 * NORM_NG) void layernorm_cols_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const float* __restrict__ bias, float eps,
                                                                       float* __restrict__ out, int C, int L) {
@@ -849,6 +1009,32 @@ __global__ void silu_mul_kernel(const float* __restrict__ ab, float* __restrict_
   const float g = ab[((int64_t)b * 2 * F + f) * L + t];
   const float u = ab[((int64_t)b * 2 * F + F + f) * L + t];
   out[((int64_t)b * F + f) * L + t] = (g / (1.0f + expf(-g))) * u;
+}
+
+// SiLU(gate) * up as operand planes [B][F/16][2][L][16]: thread = (column, channel quad)
+__global__ __launch_bounds__(256) void silu_mul_planes_kernel(const float* __restrict__ ab, bf16_t* __restrict__ outp, int F, int L) {
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63), f = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4, b = blockIdx.z;
+  if (t >= L || f >= F) return;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float g = ab[((int64_t)b * 2 * F + f + e) * L + t];
+    const float u = ab[((int64_t)b * 2 * F + F + f + e) * L + t];
+    v[e] = (g / (1.0f + expf(-g))) * u;
+  }
+  uint32_t h0, l0, h1, l1;
+  split2_f16_pk(v[0], v[1], h0, l0);
+  split2_f16_pk(v[2], v[3], h1, l1);
+  char* dst = reinterpret_cast<char*>(outp) + ((((int64_t)b * (F >> 4) + (f >> 4)) * 2) * L + t) * 32 + (f & 15) * 2;
+  *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(dst + (int64_t)L * 32) = make_uint2(l0, l1);
+}
+
+int launch_silu_mul_planes(const float* ab, bf16_t* outp, int B, int F, int L, hipStream_t s) {
+  FMI_REQUIRE(F % 16 == 0, "silu_mul planes: F %% 16");
+  hipLaunchKernelGGL(silu_mul_planes_kernel, dim3(cdiv(L, 64), F / 16, B), dim3(256), 0, s, ab, outp, F, L);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
 }
 
 int launch_silu_mul(const float* ab, float* out, int B, int F, int L, hipStream_t s) {
@@ -951,7 +1137,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 // A query's result depends only on its own position, so it is invariant under batch, total length and tiling.
 template <int QT>
 __global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int C, int L, int window, int ld, int q_lo) {
+                                                              int C, int L, int window, int ld, int q_lo,
+                                                              bf16_t* __restrict__ outp) {
   constexpr int HD = 64;
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   const int KT = QT + window - 1, RS = KT | 1;
@@ -1009,12 +1196,21 @@ __global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __res
     const float* vr = Vs + lane * RS + (lo - k0);  // lane = head dimension
     float o = 0.f;
     for (int jj = 0; jj < n; ++jj) o += pw[jj] * vr[jj];
-    out[((int64_t)b * C + h * HD + lane) * (L - q_lo) + (t - q_lo)] = o / den;
+    if (outp) {   // fp16 hi/lo operand planes [B][C/16][2][L - q_lo][16] for linear_planes_kernel
+      const int c = h * HD + lane, n = L - q_lo;
+      uint16_t hh, ll;
+      split1_f16(o / den, hh, ll);
+      char* dst = reinterpret_cast<char*>(outp) + ((((int64_t)b * (C >> 4) + (c >> 4)) * 2) * n + (t - q_lo)) * 32 + (c & 15) * 2;
+      *reinterpret_cast<uint16_t*>(dst) = hh;
+      *reinterpret_cast<uint16_t*>(dst + (int64_t)n * 32) = ll;
+    } else {
+      out[((int64_t)b * C + h * HD + lane) * (L - q_lo) + (t - q_lo)] = o / den;
+    }
   }
 }
 
 int launch_window_attn(const float* qkv, float* out, int B, int C, int L, int hd, int window, hipStream_t s, int ld,
-                       int q_lo) {
+                       int q_lo, bf16_t* outp) {
   FMI_REQUIRE(hd <= 64 && C % hd == 0, "window_attn: head_dim %d unsupported", hd);
   if (ld <= 0) ld = L;
   FMI_REQUIRE(ld >= L && q_lo >= 0 && q_lo < L, "window_attn: bad stride / query range");
@@ -1027,10 +1223,11 @@ int launch_window_attn(const float* qkv, float* out, int B, int C, int L, int hd
       FMI_CHECK_HIP(hipFuncSetAttribute((const void*)window_attn_lds_kernel<QT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)smem));
     hipLaunchKernelGGL((window_attn_lds_kernel<QT>), dim3(cdiv(nq, QT), C / hd, B), dim3(256), smem, s, qkv, out, C, L,
-                       window, ld, q_lo);
+                       window, ld, q_lo, outp);
     FMI_CHECK_HIP(hipGetLastError());
     return FMI_OK;
   }
+  FMI_REQUIRE(!outp, "window_attn: operand-plane output needs head_dim 64 and window <= 128");
   hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nq, 4), C / hd, B), dim3(256), 0, s, qkv, out, C, L, hd, window, ld, q_lo);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
