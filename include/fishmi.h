@@ -131,7 +131,8 @@ int fmi_dualar_poll_done(fmi_dualar* h, int n, const int32_t* slot_ids, int32_t*
                          void* stream);
 int fmi_dualar_release(fmi_dualar* h, int slot);
 /* Device pointer of the generated-frames buffer, int32 [max_batch][max_frames][1+num_codebooks]
- * (slot-major), so that a consumer on the same GPU (the codec) reads the codes without a host copy. */
+ * (slot-major), so that a consumer on the same GPU (the codec) reads the codes without a host copy.  Frames of a
+ * decode call still in flight: order the consumer's stream with fmi_dualar_wait, or wait with fmi_dualar_synchronize. */
 int fmi_dualar_out_ptr(fmi_dualar* h, void** out_dev, int* max_frames);
 
 /* Drop-in single-step seam = the `decode_one_token` callable
