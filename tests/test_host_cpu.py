@@ -266,3 +266,45 @@ def test_server_batch_helpers_pad_trim_and_cache():
 def test_inference_result_dataclass_matches_the_reference_fields():
     r = InferenceResult(code="final", audio=(44100, np.zeros(2, np.float32)), error=None)
     assert (r.code, r.error) == ("final", None) and r.audio[0] == 44100
+
+
+def _bare_model(vocab=300, cbs=16, ncb=3):
+    """MiDualAR without a device library: only the pure-host helpers are touched."""
+    from fish_speech_amd.dual_ar import MiDualAR
+
+    m = object.__new__(MiDualAR)
+    m.config = SimpleNamespace(vocab_size=vocab, codebook_size=cbs, num_codebooks=ncb)
+    m._cached_prompt = {}
+    return m
+
+
+def test_prompt_token_range_check_mirrors_embedding_index_errors():
+    m = _bare_model()
+    ok = torch.tensor([[299, 15, 0, 7], [0, 0, 0, 0]])
+    m._check_tokens(ok)
+    m._check_tokens(ok[:0])
+    for bad in ([[300, 0, 0, 0]], [[-1, 0, 0, 0]], [[5, 16, 0, 0]], [[5, 0, -2, 0]]):
+        with pytest.raises(IndexError):
+            m._check_tokens(torch.tensor(bad))
+
+
+def test_reusable_prefix_rules():
+    """Longest common prefix, at least one column left to run, and never across the two prefill kernel classes
+    (<= 16 rows: decode GEMV, longer: tiled GEMM -- K/V written by one are not bit-identical to the other's)."""
+    m = _bare_model()
+    g = torch.Generator().manual_seed(0)
+    base = torch.randint(0, 16, (4, 60), generator=g)
+    assert m._reusable_prefix(0, base) == 0                       # nothing cached
+    m._cached_prompt[0] = base[:, :40].clone()
+    assert m._reusable_prefix(0, base[:, :50]) == 40              # extension: the whole cached prompt
+    assert m._reusable_prefix(0, base[:, :40]) == 39              # same prompt: one column still runs
+    assert m._reusable_prefix(0, base[:, :30]) == 29              # shorter prompt
+    changed = base[:, :50].clone()
+    changed[2, 17] ^= 1
+    assert m._reusable_prefix(0, changed) == 17                   # first differing column (any row)
+    assert m._reusable_prefix(1, base[:, :50]) == 0               # another slot
+    assert m._reusable_prefix(0, base[:, :12]) == 0               # long cached, short new: other kernel class
+    m._cached_prompt[0] = base[:, :9].clone()
+    assert m._reusable_prefix(0, base[:, :14]) == 9               # both short
+    assert m._reusable_prefix(0, base[:, :30]) == 0               # short cached, long new
+    assert m._reusable_prefix(0, base[:, :1]) == 0                # a single column always runs
