@@ -74,7 +74,9 @@ int main() {
   const size_t stream_bytes = (size_t)1 << 30;
   void* big; CK(hipMalloc(&big, stream_bytes)); CK(hipMemset(big, 1, stream_bytes));
   uint32_t* sink; CK(hipMalloc((void**)&sink, 4));
+  const bool quick = getenv("GEMV_QUICK") != nullptr;   // only the GEMV variants of w13 / wo
   for (int blocks : {1024, 2048, 4096, 8192}) {
+    if (quick) break;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(256), 0, 0, (const u32x4*)big, stream_bytes / 16, sink);
     CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
@@ -84,6 +86,7 @@ int main() {
   }
   // small streaming reads (the size of one GEMV) to see the fixed per-kernel cost
   for (size_t mb : {21, 32, 50, 100}) {
+    if (quick) break;
     size_t bytes = mb << 20; hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
     for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, 0, (const u32x4*)((char*)big + (size_t)(i % 8) * (128 << 20)), bytes / 16, sink);
@@ -94,6 +97,7 @@ int main() {
                     {"wo   N=2560 K=4096 residual", 2560, 4096, EPI_RESIDUAL, false}, {"w2   N=2560 K=9728 residual", 2560, 9728, EPI_RESIDUAL, false},
                     {"head N=4096 K=2560 store+norm (fast_output / live LM head)", 4096, 2560, EPI_STORE, true}};
   for (const Shape& sh : shapes) {
+    if (quick && sh.N != 19456 && !(sh.N == 2560 && sh.K == 4096)) continue;
     const double bytes = (double)sh.N * sh.K * 2;
     const int nbuf = (int)(2.0e9 / bytes) + 1;
     std::vector<bf16_t*> wbufs(nbuf);
@@ -106,6 +110,9 @@ int main() {
     printf("%s  (%.1f MB, M=%d)\n", sh.name, bytes / 1e6, M);
     // paired activation loads (the M <= 8 path) over pairs-in-flight x tiles, then the per-tile-load path (M > 8) of the shipped shapes
     V(8, 1, 2, true); V(8, 2, 2, true); V(8, 1, 1, true); V(8, 2, 1, true); V(8, 4, 1, true); V(16, 1, 2, true); V(16, 2, 1, true);
+    // one chunk = the wave's whole k-slice in flight (K = 2560: 5 pairs per wave of 8, 10 per wave of 4; K = 4096: 8):
+    // a single exposed round trip per work-group instead of one per chunk (round-3 candidates)
+    V(8, 5, 2, true); V(8, 5, 1, true); V(4, 10, 1, true); V(4, 5, 2, true); V(8, 8, 1, true); V(8, 3, 2, true);
     VX(8, 1, 2); VX(8, 2, 1);
     { float us = run_shipped(sh, wbufs, x, nw, res, out, M, iters); printf("  shipped launcher (launch_linear_skinny) : %7.2f us  %6.0f GB/s\n", us, bytes / us * 1e-3); }
     for (auto p : wbufs) hipFree(p);
