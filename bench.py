@@ -26,10 +26,22 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-# HBM bytes fetched per decode frame at batch 8, from the separate rocprofv3 --pmc FETCH_SIZE pass
-# (profiles/r02_pmc_fetch_decode.txt; KiB x 1024 x 2 = the gfx950 correction of MI355X_MICROARCH.md).
-# PMC counters cannot be collected inside a timed run, so the figure is carried here with its provenance.
-PMC_FETCH_BYTES_PER_FRAME = 15.64e9
+# HBM bytes fetched per decode frame at batch 8 come from a separate rocprofv3 --pmc FETCH_SIZE pass (PMC counters
+# cannot be collected inside a timed run): tools/make_profiles.sh runs it and tools/pmc_traffic.py writes the figure,
+# with its provenance, into this committed file (KiB x 1024 x 2 = the gfx950 correction of MI355X_MICROARCH.md).
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def pmc_traffic(batch, frames, int8):
+    """-> (bytes per decode frame or None, provenance string)."""
+    try:
+        with open(PMC_TRAFFIC_JSON) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/pmc_traffic.json missing"
+    if int8 or batch != d.get("batch") or frames != 215:
+        return None, "PMC pass was collected for the headline configuration only"
+    return float(d["bytes_per_decode_frame"]), d.get("source", "")
 
 FRAME_LEN = 2048          # samples per frame (modded_dac.py:833,861)
 SAMPLE_RATE = 44100
@@ -149,11 +161,11 @@ def run_step(model, codec, prompts, samp_seeds, device):
     return codes, wav
 
 
-def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=5, codec_frames=32):
+def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=32, codec_frames=N_FRAMES):
     """The oracle (CPU restatement of the reference path, kind 'port') timed on this box's host cores on a
-    bounded sample: Dual-AR prefill of one 200-token prompt + n_frames decode frames (batch 1 -- the
-    reference cannot batch), and codec decode of codec_frames frames; both extrapolated linearly to one
-    10 s utterance."""
+    bounded sample of the same workload: Dual-AR prefill of one 200-token prompt + n_frames decode frames at context
+    200.. (batch 1 -- the reference cannot batch), extrapolated linearly to 215 frames, and the codec decode of the
+    FULL 215 frames of one utterance."""
     from oracle import dac as OD
     from oracle import dual_ar as O
 
@@ -168,7 +180,7 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=5, codec_frames=32):
     all_threads = torch.get_num_threads()
     sweep = {}
     O.generate(orc, prompt[:, :8], 1, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)  # page in
-    for nt in sorted({t for t in (8, 16, 32, 64, 128, all_threads) if t <= all_threads}):
+    for nt in sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         O.generate(orc, prompt[:, :8], 3, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
@@ -184,30 +196,111 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=5, codec_frames=32):
     per_frame = max(t_all - t_prefill, 1e-9) / n_frames
     t_ar = t_prefill + (N_FRAMES - 1) * per_frame
     del orc, st
-    t_codec, note = 0.0, "codec not included"
+    t_codec, note, cbest = 0.0, "codec not included", best
     if codec_state_dev is not None:
         ccfg = OD.DacConfig()
         cst = {k: v.float().cpu() for k, v in codec_state_dev.items()}
         corc = OD.DacOracle(ccfg, cst)
-        codes = OD.make_codes(ccfg, 1, codec_frames, seed=1)
         with torch.no_grad():
-            t_c = 1e30
-            for nt in sorted({t for t in (16, 64, all_threads) if t <= all_threads}):
+            csweep = {}
+            small = OD.make_codes(ccfg, 1, 16, seed=1)
+            for nt in sorted({t for t in (16, 32, 64, all_threads) if t <= all_threads}):
                 torch.set_num_threads(nt)
                 t0 = time.perf_counter()
-                corc.from_indices(codes.clone())
-                t_c = min(t_c, time.perf_counter() - t0)
+                corc.from_indices(small.clone())
+                csweep[nt] = time.perf_counter() - t0
+            cbest = min(csweep, key=csweep.get)
+            torch.set_num_threads(cbest)
+            codes = OD.make_codes(ccfg, 1, codec_frames, seed=1)
+            t0 = time.perf_counter()
+            corc.from_indices(codes.clone())
+            t_c = time.perf_counter() - t0
         t_codec = t_c * N_FRAMES / codec_frames
-        note = f"codec decode {codec_frames} frames {t_c:.2f}s (fp32)"
+        note = f"codec decode of {codec_frames} frames {t_c:.2f}s (fp32, {cbest} threads)"
     torch.set_num_threads(all_threads)
     return {
-        "value": round(10.0 / (t_ar + t_codec), 5), "unit": "audio-sec/s", "cores": best,
+        "value": round(10.0 / (t_ar + t_codec), 5), "unit": "audio-sec/s", "cores": max(best, cbest),
         "kind": "port",
         "sample": f"oracle on torch CPU, batch 1, {best} threads (best of sweep "
                   f"{ {k: round(v, 2) for k, v in sweep.items()} } s/frame-ish, host has {os.cpu_count()} cpus): "
                   f"prefill {PROMPT_T} tokens {t_prefill:.2f}s + {n_frames} decode "
-                  f"frames at {per_frame:.3f}s/frame (bf16); {note}; extrapolated to one {N_FRAMES}-frame utterance",
+                  f"frames at context {PROMPT_T}..{PROMPT_T + n_frames} at {per_frame:.3f}s/frame (bf16), extrapolated to "
+                  f"{N_FRAMES} frames; {note}",
     }
+
+
+def measure_prefill(model, prompts, seeds, reps=3):
+    """Median wall time (HIP events on torch's stream, which the library orders itself against) of the prefill call of
+    the step: 8 x 200 prompt rows through 36 layers (tiled MFMA GEMM + MFMA flash attention) plus the first frame's
+    head, sampler and fast-AR chain."""
+    import statistics
+
+    sp = [model._sampling(0.7, 0.7, 30, s, True) for s in seeds]
+    slots = list(range(len(prompts)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        e0.record()
+        model.prefill(slots, prompts, [2] * len(prompts), sp)
+        model.wait_stream()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+        for i in slots:
+            model.release(i)
+    return statistics.median(ts[1:])
+
+
+def prefill_roofline(cfg, prefill_ms):
+    """MFMA-bound part of the step: the slow transformer over the prompt rows.  flops = 2 x slow-layer weights x rows
+    + causal attention 4 H D T^2 / 2 per prompt and layer; the measured time also contains the first
+    frame's fast-AR chain (HBM-bound, ~half a decode frame), so `frac` is a lower bound for the GEMM + attention."""
+    rows = BATCH * PROMPT_T
+    d, ffn = cfg.dim, cfg.intermediate_size
+    qkv = (cfg.n_head + 2 * cfg.n_local_heads) * cfg.head_dim
+    per_layer = qkv * d + d * cfg.n_head * cfg.head_dim + 3 * ffn * d
+    flops = 2.0 * cfg.n_layer * per_layer * rows + BATCH * cfg.n_layer * 4.0 * cfg.n_head * cfg.head_dim * PROMPT_T * PROMPT_T / 2
+    ach = flops / (prefill_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "kernel": "prefill: linear_tiled_lds_kernel<0|1|2> + attn_prefill_mfma_kernel over 8 x 200 rows, 36 layers "
+                      "(time includes the first frame's head + fast-AR chain)",
+            "flops_per_launch": flops, "avg_launch_ms": round(prefill_ms, 3), "traffic": None}
+
+
+def codec_roofline(codec_ms):
+    """Codec decode of 8 x 215 frames on the fp16 matrix cores: useful flops (1.454 TFLOP per 215-frame
+    utterance) and issued flops (the two-term fp16 split runs 3 MFMA products per useful one)."""
+    useful = BATCH * 1.454e12 * N_FRAMES / 215
+    ach = useful / (codec_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 1), "issued": round(3 * ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(ach / 2500.0, 4), "frac_issued": round(3 * ach / 2500.0, 4),
+            "kernel": "conv_mfma_bf16_kernel<..., NP = 2> (fp16 two-term split, fp32-class results) + linear_planes_kernel",
+            "flops_per_launch": useful, "avg_launch_ms": round(codec_ms, 3), "traffic": None}
+
+
+def measure_encode(codec, device):
+    """DAC.encode throughput (extract_vq.py's job): one 3 s clip and a batch of 64 x 3 s clips (fp32 matrix cores)."""
+    g = torch.Generator(device=device).manual_seed(7)
+    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, b in (("clip_3s", 1), ("batch64_3s", 64)):
+        a = 0.1 * torch.randn(b, 1, 3 * SAMPLE_RATE, generator=g, device=device)
+        lens = torch.full((b,), 3 * SAMPLE_RATE, device=device, dtype=torch.long)
+        codec.encode(a, lens)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(2):
+            e0.record()
+            codec.encode(a, lens)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = min(ts)
+        out[name] = {"ms": round(ms, 2), "audio_sec_per_s": round(3.0 * b / (ms * 1e-3), 1),
+                     "tflops_useful": round(2 * 115.8e9 * b / (ms * 1e-3) / 1e12, 1)}
+    out["note"] = "fp32 matrix cores (v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s); 115.8 useful GMAC per 3 s clip (SURVEY 8d)"
+    return out
 
 
 def _sync(device):
@@ -359,6 +452,9 @@ def main():
                     help="weight-only int8 checkpoint of the same model (NOT the headline number: reduced precision)")
     ap.add_argument("--no-codec", action="store_true", help="debug: Dual-AR only (INVALID as a result)")
     ap.add_argument("--frames", type=int, default=215, help="debug: fewer frames (INVALID as a result)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (backend nccl = RCCL) even at --gpus 1 and run the arena broadcast "
+                         "and the reductions of the N > 1 path through it (exercises RCCL inside a 1-GPU lease)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra measurements (configs 1, 3, 4 of BASELINE.json) after the timed region")
     args = ap.parse_args()
@@ -373,9 +469,16 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
+        if "MASTER_ADDR" not in os.environ:   # --force-dist without a launcher: a one-rank rendezvous on loopback
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     # the library ships prebuilt in-tree; if it is stale only one process per node compiles it
@@ -394,7 +497,7 @@ def main():
     if rank == 0:
         state = synthetic_state_on_device(cfg, device)
         model.load_state_dict(quantize_state_int8_on_device(state) if args.int8 else state)
-    if world > 1:  # the only collective of the path: one broadcast of the packed weight arena (xGMI)
+    if dist:  # the only collective of the path: one broadcast of the packed weight arena (xGMI)
         from fish_speech_amd.dist import broadcast_arena
 
         broadcast_arena(model, src=0)
@@ -409,7 +512,7 @@ def main():
         if rank == 0:
             codec_state = synthetic_codec_state(ccfg, device)
             codec.load_folded_state(codec_state)
-        if world > 1:
+        if dist:
             from fish_speech_amd.dist import broadcast_arena
 
             broadcast_arena(codec, src=0)
@@ -448,6 +551,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # untimed side measurements for the other two rooflines (after the timed region, same objects)
+    prefill_ms = measure_prefill(model, prompts, seeds)
     audio_s = world * BATCH * N_FRAMES * FRAME_LEN / SAMPLE_RATE * args.steps
     mean_ctx = PROMPT_T + N_FRAMES / 2
     bytes_frame = algorithmic_bytes_per_frame(cfg, BATCH, mean_ctx, int8=args.int8)
@@ -474,11 +579,17 @@ def main():
                          "codec_decode_batch": round(sum(codec_ms) / len(codec_ms), 2) if codec_ms else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 4),
-                     "traffic": PMC_FETCH_BYTES_PER_FRAME if (N_FRAMES == 215 and BATCH == 8 and not args.int8) else None,
+                     "traffic": pmc_traffic(BATCH, N_FRAMES, args.int8)[0],
+                     "traffic_source": pmc_traffic(BATCH, N_FRAMES, args.int8)[1],
                      "kernel": "decode frame: 302 linear_skinny_kernel launches (weight streaming) + 36 attention, 40 fast-attention, "
                                "10 sampler launches, replayed as one hipGraph",
                      "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},
     }
+    out["roofline_prefill"] = prefill_roofline(cfg, prefill_ms)
+    if codec_ms:
+        out["roofline_codec"] = codec_roofline(sum(codec_ms) / len(codec_ms))
+    if not args.no_extras and N_FRAMES == 215 and codec is not None and world == 1:
+        out["encode"] = measure_encode(codec, device)
     if not args.no_extras and N_FRAMES == 215:
         # untimed extras: the other single-node configurations of BASELINE.json, measured with the same objects
         extras = {"config3_mixed_lengths": run_config4(model, codec, cfg, rank, world, dist, device)}

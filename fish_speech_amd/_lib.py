@@ -87,6 +87,7 @@ _SIGS = {
     "fmi_dac_finalize_weights": (C.c_int, [_P, _P]),
     "fmi_dac_weights_ready": (C.c_int, [_P]),
     "fmi_dac_set_precision": (C.c_int, [_P, _I]),
+    "fmi_dac_fp16_overflow": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "fmi_dac_decode": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "fmi_dac_decode_latent": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "fmi_dac_decode_tail": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),

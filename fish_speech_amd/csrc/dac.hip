@@ -856,6 +856,13 @@ int fmi_dac_set_precision(fmi_dac* h, int planes) {
   return FMI_OK;
 }
 
+int fmi_dac_fp16_overflow(fmi_dac* h, int* overflowed) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h && overflowed, "null argument");
+  return read_clear_f16_overflow(overflowed, h->stream);
+}
+
 int fmi_dac_weights_ready(fmi_dac* h) {
   FMI_REQUIRE(h, "null handle");
   h->ready = true;

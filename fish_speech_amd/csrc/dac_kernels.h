@@ -112,4 +112,7 @@ struct VqArgs {
 };
 int launch_vq_step(const VqArgs& a, hipStream_t s);
 
+// sticky fp16-split overflow flag (dac_kernels.hip: g_f16_overflow): waits for `s`, returns the flag and clears it
+int read_clear_f16_overflow(int* flag, hipStream_t s);
+
 }  // namespace fmi

@@ -307,9 +307,18 @@ __device__ inline void split3_pk(float x0, float x1, uint32_t& h, uint32_t& m, u
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float F16_LO_SCALE = 2048.0f;
+constexpr float F16_MAX = 65504.0f;
+// Sticky: set when a value outside the fp16 range reached the split (fmi_dac_fp16_overflow reads and clears it).  The
+// split SATURATES there (both terms clamped to the largest finite fp16, one v_med3_f32 each) instead of producing
+// inf - inf = NaN that would spread through the whole waveform; the caller can then redo the call with precision 0.
+__device__ int g_f16_overflow = 0;
 __device__ inline void split2_f16_pk(float x0, float x1, uint32_t& h, uint32_t& l) {
+  if (fmaxf(fabsf(x0), fabsf(x1)) > F16_MAX) g_f16_overflow = 1;
+  x0 = __builtin_amdgcn_fmed3f(x0, -F16_MAX, F16_MAX);
+  x1 = __builtin_amdgcn_fmed3f(x1, -F16_MAX, F16_MAX);
   const f16x2 hv = {(_Float16)x0, (_Float16)x1};
-  const float r0 = (x0 - (float)hv[0]) * F16_LO_SCALE, r1 = (x1 - (float)hv[1]) * F16_LO_SCALE;
+  const float r0 = __builtin_amdgcn_fmed3f((x0 - (float)hv[0]) * F16_LO_SCALE, -F16_MAX, F16_MAX);
+  const float r1 = __builtin_amdgcn_fmed3f((x1 - (float)hv[1]) * F16_LO_SCALE, -F16_MAX, F16_MAX);
   const f16x2 lv = {(_Float16)r0, (_Float16)r1};
   h = *reinterpret_cast<const uint32_t*>(&hv);
   l = *reinterpret_cast<const uint32_t*>(&lv);
@@ -1448,6 +1457,18 @@ int launch_final_conv_tanh(const float* x, const float* alpha, const float* w, c
   hipLaunchKernelGGL(final_conv_tanh_kernel, dim3(cdiv(L - col0, 256), B), dim3(256), smem, s, x, alpha, w, bias, out,
                      C, L, col0);
   FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+int read_clear_f16_overflow(int* flag, hipStream_t s) {
+  int v = 0;
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  FMI_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_overflow), sizeof(int)));
+  if (v) {
+    const int zero = 0;
+    FMI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_f16_overflow), &zero, sizeof(int)));
+  }
+  *flag = v;
   return FMI_OK;
 }
 

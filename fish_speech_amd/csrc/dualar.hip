@@ -25,6 +25,9 @@ struct LayerW {
   // the bf16 pointers above then hold the exactly dequantised weights for the prefill / M > 8 paths
   int8_t *q_wqkv = nullptr, *q_wo = nullptr, *q_w13 = nullptr, *q_w2 = nullptr;
   bf16_t *s_wqkv = nullptr, *s_wo = nullptr, *s_w13 = nullptr, *s_w2 = nullptr;
+  // row-balanced decode copies (outside the arena, derived on every rank after the weights are in place):
+  // streamed by the M <= 8 decode GEMV instead of the 16-row tiles where those leave CUs idle (skinny_row_plan)
+  bf16_t *r_wqkv = nullptr, *r_wo = nullptr, *r_w13 = nullptr, *r_w2 = nullptr;
 };
 
 struct Dims {
@@ -74,6 +77,8 @@ struct fmi_dualar {
   // sampler; 9 of the 40 fast wqkv GEMVs of a frame (31.5 MB each at the S2 shape) become 8-row gathers
   bf16_t *qkv0_tab = nullptr, *qkv0_pre = nullptr;
   bool qkv0_tried = false;
+  bool rows_tried = false;             // row-balanced decode copies (LayerW::r_*) derived
+  std::vector<void*> row_copies;       // their allocations
   bool trace = false, use_graph = true, ignore_eos = false;
   bool force_tiled = false;
   int attn_impl = 1;   // prefill attention: 1 = MFMA flash kernel with LDS-staged K/V tiles, 0 = VALU kernel (A/B parity)
@@ -224,6 +229,23 @@ void drop_graphs(fmi_dualar* h) {
   h->graphs.clear();
 }
 
+// Tables and copies DERIVED from the weights (row-balanced decode copies, fast layer-0 q|k|v table) are dropped when a
+// tensor is (re)loaded after they were built; the next prefill rebuilds them.
+int invalidate_derived(fmi_dualar* h) {
+  if (!h->rows_tried && !h->qkv0_tried) return FMI_OK;
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  drop_graphs(h);
+  for (void* p : h->row_copies) hipFree(p);
+  h->row_copies.clear();
+  for (auto* LL : {&h->L, &h->FL})
+    for (auto& w : *LL) w.r_wqkv = w.r_wo = w.r_w13 = w.r_w2 = nullptr;
+  if (h->qkv0_tab) hipFree(h->qkv0_tab);
+  if (h->qkv0_pre) hipFree(h->qkv0_pre);
+  h->qkv0_tab = h->qkv0_pre = nullptr;
+  h->rows_tried = h->qkv0_tried = false;
+  return FMI_OK;
+}
+
 int ensure_rows(fmi_dualar* h, int rows) {
   if (h->ws.rows >= rows) return FMI_OK;
   FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
@@ -251,10 +273,10 @@ int ensure_rows(fmi_dualar* h, int rows) {
 // out = linear(norm?(x)) for M rows; picks the skinny (fused norm) or tiled path.
 int linear(fmi_dualar* h, const bf16_t* x, int ldx, const bf16_t* wp, const bf16_t* norm_w, const bf16_t* res,
            int ldr, bf16_t* out, int ldo, int M, int N, int K, int epi, hipStream_t s, const int8_t* wq = nullptr,
-           const bf16_t* scale = nullptr) {
+           const bf16_t* scale = nullptr, const bf16_t* wr = nullptr) {
   LinearArgs a{};
   a.wp = wp; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = h->cfg.norm_eps; a.res = res; a.ldr = ldr;
-  a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epi = epi; a.wq = wq; a.scale = scale;
+  a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epi = epi; a.wq = wq; a.scale = scale; a.wr = wr;
   // h->force_tiled: the few suffix rows of a resumed prefill must go through the kernel a full prefill of the
   // whole prompt would have used for them (the tiled GEMM: a row's bits do not depend on how many rows run along)
   if (M <= 16 && !h->force_tiled) {
@@ -277,7 +299,7 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
                const int32_t* row_pos, hipStream_t s) {
   const Dims& d = h->slow;
   Workspace& ws = h->ws;
-  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, rows, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
+  FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, rows, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv, w.r_wqkv));
   AttnArgs a{};
   a.qkv = ws.qkv; a.q = ws.q; a.out = ws.ao; a.kpool = h->kpool[layer]; a.vpool = h->vpool[layer];
   a.qnw = h->cfg.attention_qk_norm ? w.q_norm : nullptr;
@@ -295,9 +317,9 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
     else FMI_CHECK(launch_attn(a, s));
     h->launches += 2;
   }
-  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo));
-  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
-  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2));
+  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo, w.r_wo));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13, w.r_w13));
+  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2, w.r_w2));
   return FMI_OK;
 }
 
@@ -306,7 +328,7 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
   const Dims& d = h->fast;
   Workspace& ws = h->ws;
   if (!qkv_pre)
-    FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
+    FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv, w.r_wqkv));
   FastAttnArgs a{};
   a.qkv = qkv_pre ? qkv_pre : ws.qkv; a.out = ws.ao; a.kc = h->fkc[layer]; a.vc = h->fvc[layer];
   a.qnw = h->cfg.fast_attention_qk_norm ? w.q_norm : nullptr;
@@ -316,9 +338,9 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
   FMI_CHECK(launch_fast_attn(a, s));
   h->launches += 1;
   if (kv_only) return FMI_OK;  // only this layer's K/V at `pos` were needed
-  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo));
-  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
-  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2));
+  FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo, w.r_wo));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13, w.r_w13));
+  FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2, w.r_w2));
   return FMI_OK;
 }
 
@@ -395,9 +417,43 @@ int decode_frame(fmi_dualar* h, int B, hipStream_t s, bool head_only = false) {
   return FMI_OK;
 }
 
+// Row-balanced decode copies of the projection matrices whose 16-row tiling leaves CUs idle at the decode shapes
+// (dualar_kernels.h: skinny_row_plan): derived from the packed arena once the weights are in place, on every rank
+// (they are a permutation of arena bytes, so they do not travel with the broadcast).  FMI_NO_ROWS=1 keeps the 16-row
+// tiles (A/B runs).  Costs one extra copy of the layer matrices in HBM (9.1 GB at the S2-Pro shape, of 288 GB).
+int ensure_row_copies(fmi_dualar* h) {
+  if (h->rows_tried || !h->ready) return FMI_OK;
+  h->rows_tried = true;
+  static const bool off = []() { const char* e = getenv("FMI_NO_ROWS"); return e && atoi(e) != 0; }();
+  if (off || h->cfg.weight_int8) return FMI_OK;
+  hipStream_t s = h->stream;
+  auto derive = [&](const bf16_t* packed, bf16_t** dst, int N, int K, int epi, bool norm) -> int {
+    if (!skinny_rows_supported(N, K, epi, norm)) return FMI_OK;
+    const RowPlan p = skinny_row_plan(N, K, epi);
+    void* mem = nullptr;
+    FMI_CHECK_HIP(hipMalloc(&mem, (size_t)p.elems * 2));
+    h->row_copies.push_back(mem);
+    FMI_CHECK(launch_repack_rows(packed, (bf16_t*)mem, N, K, epi, p, s));
+    *dst = (bf16_t*)mem;
+    return FMI_OK;
+  };
+  auto layer = [&](LayerW& w, const Dims& d) -> int {
+    FMI_CHECK(derive(w.wqkv, &w.r_wqkv, d.qkv, d.dim, EPI_STORE, true));
+    FMI_CHECK(derive(w.wo, &w.r_wo, d.dim, d.H * d.D, EPI_RESIDUAL, false));
+    FMI_CHECK(derive(w.w13, &w.r_w13, 2 * d.ffn, d.dim, EPI_SILU, true));
+    return derive(w.w2, &w.r_w2, d.dim, d.ffn, EPI_RESIDUAL, false);
+  };
+  for (auto& w : h->L) FMI_CHECK(layer(w, h->slow));
+  for (auto& w : h->FL) FMI_CHECK(layer(w, h->fast));
+  FMI_CHECK_HIP(hipStreamSynchronize(s));
+  drop_graphs(h);
+  return FMI_OK;
+}
+
 // Tabulate fast layer 0's wqkv(rmsnorm(fast_embeddings[code])) for every code, 8 codes per launch of the decode
 // GEMV itself (its row results do not depend on the batch they are computed in, tests/test_dualar_gpu.py).
 int ensure_qkv0_table(fmi_dualar* h) {
+  FMI_CHECK(ensure_row_copies(h));
   if (h->qkv0_tried || !h->ready || h->max_batch == 0) return FMI_OK;
   h->qkv0_tried = true;
   static const bool off = []() { const char* e = getenv("FMI_NO_QKV0"); return e && atoi(e) != 0; }();
@@ -412,7 +468,7 @@ int ensure_qkv0_table(fmi_dualar* h) {
   const int saved = h->launches;
   for (int code = 0; code < c.codebook_size; code += 8)
     FMI_CHECK(linear(h, h->fast_emb + (int64_t)code * d.dim, d.dim, w.wqkv, w.attn_norm, nullptr, 0,
-                     h->qkv0_tab + (int64_t)code * d.qkv, d.qkv, 8, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv));
+                     h->qkv0_tab + (int64_t)code * d.qkv, d.qkv, 8, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv, w.r_wqkv));
   h->launches = saved;
   FMI_CHECK_HIP(hipStreamSynchronize(s));
   drop_graphs(h);
@@ -533,6 +589,7 @@ void fmi_dualar_destroy(fmi_dualar* h) {
                   h->qkv0_tab, h->qkv0_pre};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  for (void* p : h->row_copies) hipFree(p);
   hipEventDestroy(h->ev_in);
   hipEventDestroy(h->ev_out);
   hipEventDestroy(h->ev_t0);
@@ -546,6 +603,7 @@ int fmi_dualar_load_tensor(fmi_dualar* h, const char* name_c, const void* src, i
   FMI_REQUIRE(h && name_c && src, "null argument");
   const std::string name(name_c);
   const fmi_dualar_config& c = h->cfg;
+  FMI_CHECK(invalidate_derived(h));
   FMI_CHECK(sync_in(h, stream));
   hipStream_t s = h->stream;
   const bf16_t* dsrc = (const bf16_t*)src;
@@ -610,6 +668,7 @@ int fmi_dualar_load_tensor_int8(fmi_dualar* h, const char* name_c, const void* w
   FMI_REQUIRE(cols % 64 == 0, "int8 linears need K %% 64 == 0 (got %lld)", (long long)cols);
   const std::string name(name_c);
   const fmi_dualar_config& c = h->cfg;
+  FMI_CHECK(invalidate_derived(h));
   FMI_CHECK(sync_in(h, stream));
   hipStream_t s = h->stream;
   const int64_t n = rows * cols;
@@ -1175,7 +1234,19 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
   a.wp = packed; a.x = (const bf16_t*)x_dev; a.ldx = K; a.norm_w = (const bf16_t*)norm_w_dev; a.eps = eps;
   a.res = (const bf16_t*)residual_dev; a.ldr = n_out; a.out = (bf16_t*)out_dev; a.ldo = n_out; a.M = M; a.N = N;
   a.K = K; a.epi = epilogue;
-  const bool skinny = force_path == 1 || (force_path == 0 && M <= 16);  // 2: tiled (LDS-staged), 5: tiled, operands straight from L2
+  // 2: tiled (LDS-staged), 5: tiled, operands straight from L2, 6: skinny on the row-balanced copy (must exist)
+  const bool skinny = force_path == 1 || force_path == 6 || (force_path == 0 && M <= 16);
+  bf16_t* rowcopy = nullptr;
+  if (rc == FMI_OK && force_path == 6) {
+    if (M > 8 || !skinny_rows_supported(N, K, epilogue, norm_w_dev != nullptr)) {
+      rc = set_error(FMI_EINVAL, "no row-balanced variant for M=%d N=%d K=%d epilogue=%d", M, N, K, epilogue);
+    } else {
+      const RowPlan p = skinny_row_plan(N, K, epilogue);
+      if (hipMalloc((void**)&rowcopy, (size_t)p.elems * 2) != hipSuccess) rc = set_error(FMI_EHIP, "hipMalloc");
+      if (rc == FMI_OK) rc = launch_repack_rows(packed, rowcopy, N, K, epilogue, p, s);
+      a.wr = rowcopy;
+    }
+  }
   if (rc == FMI_OK) {
     if (skinny) {
       rc = launch_linear_skinny(a, s);
@@ -1192,6 +1263,7 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
   hipStreamSynchronize(s);
   hipFree(packed);
   if (xn) hipFree(xn);
+  if (rowcopy) hipFree(rowcopy);
   return rc;
 }
 

@@ -72,6 +72,66 @@ int launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int interle
   return FMI_OK;
 }
 
+// ---- row-balanced decode copy (linear_skinny_kernel<..., ROWS < 16>) ------------------------------------------------
+// [tile][K/32][4 lane groups][ROWS rows][8]: tile t, k-tile j, lane group kg, row b holds the 8 weights the 16-row
+// layout keeps at (row, k-tile j, lane group kg) -- same k permutation, so the activation operand logic is shared.
+RowPlan skinny_row_plan(int N, int K, int epi) {
+  RowPlan p{false, 16, 1, 0, 0, 0};
+  constexpr int CUS = 256;
+  if ((K % 64) != 0 || K < 1024) return p;   // paired k-tiles only; tiny test models keep the 16-row tiles
+  if (epi == EPI_SILU) {
+    const int half = N / 2;
+    if (N % 2 || half % (2 * CUS) != 0) return p;
+    const int g = half / (2 * CUS);          // gate rows per work-group, two work-groups per CU
+    if (g < 1 || g > 32 || g % 16 == 0) return p;
+    const int pairs = (g + 15) / 16, rows = (g + pairs - 1) / pairs;
+    p = {true, rows, 2 * pairs, 2 * CUS, g, 0};
+  } else {
+    if (N % CUS != 0) return p;
+    const int per = N / CUS;                 // rows per CU
+    if (per < 1 || per > 32 || per % 16 == 0) return p;
+    const int tiles = (per + 15) / 16;
+    if (per % tiles != 0) return p;
+    p = {true, per / tiles, tiles, CUS, 0, 0};
+  }
+  p.elems = (int64_t)p.wgs * p.tiles * p.rows * K;
+  return p;
+}
+
+__global__ void repack_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K, int silu,
+                                   int rows, int tiles, int grp_rows, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 16-byte chunk of dst
+  if (idx >= total) return;
+  const int KT = K >> 5;
+  const int b = (int)(idx % rows);
+  const int kg = (int)((idx / rows) & 3);
+  const int j = (int)((idx / (4 * rows)) % KT);
+  const int tile = (int)(idx / ((int64_t)4 * rows * KT));
+  int nd = -1;                                                          // row of the 16-row packed source
+  if (silu) {
+    const int wg = tile / tiles, t = tile % tiles;
+    const int lr = (t >> 1) * rows + b;
+    if (lr < grp_rows) {
+      const int n = wg * grp_rows + lr;                                 // gate / up row index
+      nd = (n >> 4) * 32 + (t & 1) * 16 + (n & 15);
+    }
+  } else {
+    nd = tile * rows + b;
+  }
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (nd >= 0 && nd < N) v = *reinterpret_cast<const uint4*>(src + ((int64_t)(nd >> 4) * KT + j) * 512 + (kg * 16 + (nd & 15)) * 8);
+  *reinterpret_cast<uint4*>(dst + idx * 8) = v;
+}
+
+int launch_repack_rows(const bf16_t* packed16, bf16_t* dst, int N, int K, int epi, const RowPlan& plan, hipStream_t s) {
+  FMI_REQUIRE(plan.ok, "repack_rows: no row-balanced plan for N=%d K=%d", N, K);
+  const int64_t total = plan.elems / 8;
+  hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed16, dst, N, K,
+                     epi == EPI_SILU ? 1 : 0, plan.rows, plan.tiles, plan.grp_rows, total);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
 __global__ void pack_weight_int8_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst, int N, int K,
                                         int interleave) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 elements
@@ -338,10 +398,18 @@ __device__ inline float dpp_row_shl8(float v) {  // lane n of every 16-lane row 
 // load per lane brings both k-tiles of a pair, converted to bf16 in registers (exact: |v| <= 128) right before the
 // same MFMAs -- the products, their order and hence the result bits equal the bf16 kernel on the dequantised
 // weights, at half the streamed bytes.  a.scale (any variant) applies the per-row scale of the int8 linear.
-template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool PAIRX, bool NT = true, bool Q8 = false>
+//
+// ROWS < 16 (row-balanced decode copy, launch_repack_rows): a tile carries only ROWS weight rows, so that N / ROWS
+// tiles divide evenly over the 256 CUs (N = 2560: 256 work-groups of 10 rows instead of 160 of 16).  The MFMA still
+// multiplies a 16-row A operand: lanes of rows ROWS..15 re-read row ROWS-1 (same cache lines, no extra request) and
+// their products land in accumulator rows nobody reads.  Rows 0..ROWS-1 see the same products in the same order as
+// in the 16-row layout, so the result bits do not depend on ROWS.
+template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool PAIRX, bool NT = true, bool Q8 = false, int ROWS = 16>
 __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a) {
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
   static_assert(!Q8 || PAIRX, "the int8 stream is the M <= 8 decode path");
+  static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || !Q8), "row-balanced tiles: bf16 only");
+  constexpr int TSTRIDE = ROWS * 4;   // u32x4 per (tile, k-tile): ROWS rows x 4 lane groups
   __shared__ float red[WAVES][TILES][256];
   __shared__ float s_rstd[16];
 
@@ -356,7 +424,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
     wrow[t] = Q8 ? reinterpret_cast<const u32x4*>(a.wq) + ((int64_t)(tile0 + t) * P) * 64 + lane
-                 : wp + ((int64_t)(tile0 + t) * KT) * 64 + lane;
+                 : wp + ((int64_t)(tile0 + t) * KT) * TSTRIDE + (ROWS == 16 ? lane : g * ROWS + min(b, ROWS - 1));
 
   // the first chunk of weight tiles is issued BEFORE the RMSNorm prologue so that HBM latency overlaps
   // the row statistics
@@ -370,8 +438,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
         if (Q8) {
           wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(p0 + u) * 64);
         } else {
-          wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u)) * 64);
-          wa[t][u][1] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u) + 1) * 64);
+          wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u)) * TSTRIDE);
+          wa[t][u][1] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u) + 1) * TSTRIDE);
         }
       }
   };
@@ -477,8 +545,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
         const u32x4 q = wload<NT>(wrow[t] + (int64_t)p * 64);
         unpack_q8(q, w0, w1);
       } else {
-        w0 = wload<NT>(wrow[t] + (int64_t)(2 * p) * 64);
-        w1 = wload<NT>(wrow[t] + (int64_t)(2 * p + 1) * 64);
+        w0 = wload<NT>(wrow[t] + (int64_t)(2 * p) * TSTRIDE);
+        w1 = wload<NT>(wrow[t] + (int64_t)(2 * p + 1) * TSTRIDE);
       }
       acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), x0, acc0[t], 0, 0, 0);
       acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), x1, acc1[t], 0, 0, 0);
@@ -502,7 +570,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 wv = wload<NT>(wrow[t] + (int64_t)kt * 64);
+      u32x4 wv = wload<NT>(wrow[t] + (int64_t)kt * TSTRIDE);
       acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc0[t], 0, 0, 0);
     }
   }
@@ -513,7 +581,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 
   if (tid < 256) {
     const int bb = tid >> 4, r = tid & 15;  // consecutive threads -> consecutive output columns
-    if (bb < a.M) {
+    if (bb < a.M && r < ROWS) {
       const int ridx = (((r >> 2) * 16) + bb) * 4 + (r & 3);
       float v[TILES];
 #pragma unroll
@@ -526,17 +594,21 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
       }
       if (EPI == EPI_STORE) {
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) a.out[(int64_t)bb * a.ldo + (tile0 + t) * 16 + r] = f2bf(v[t]);
+        for (int t = 0; t < TILES; ++t) a.out[(int64_t)bb * a.ldo + (tile0 + t) * ROWS + r] = f2bf(v[t]);
       } else if (EPI == EPI_RESIDUAL) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-          const int n = (tile0 + t) * 16 + r;
+          const int n = (tile0 + t) * ROWS + r;
           a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + v[t]);
         }
       } else {  // SwiGLU: even tiles = gate rows, odd tiles = up rows (llama.py:987)
 #pragma unroll
         for (int t = 0; t < TILES; t += 2) {
-          const int n = ((tile0 + t) >> 1) * 16 + r;
+          // row-balanced copy: a work-group owns a.grp_rows consecutive gate rows (and their up rows) in TILES / 2
+          // tile pairs of ROWS rows, the last pair padded (launch_repack_rows)
+          const int lr = (t >> 1) * ROWS + r;
+          if (ROWS != 16 && lr >= a.grp_rows) continue;
+          const int n = ROWS == 16 ? ((tile0 + t) >> 1) * 16 + r : (int)blockIdx.x * a.grp_rows + lr;
           float gate = rbf(silu_f(v[t]));
           float up = v[t + 1 < TILES ? t + 1 : t];
           a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
@@ -571,6 +643,28 @@ static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
   return FMI_OK;
 }
 
+// Row-balanced variants (M <= 8, bf16): the instantiations that exist, i.e. the S2-Pro decode shapes whose 16-row
+// tilings leave CUs idle -- wo / w2 (N = 2560: 10 rows x 256 work-groups), wqkv (N = 6144: 2 x 12 rows x 256) and
+// w1|w3 (N = 2 x 9728: 19 gate + 19 up rows x 512 work-groups, as 2 x (10 + 10) with one zero row per pair).
+template <int WAVES, int UNR, int TILES, int ROWS, int EPI_, bool NORM_>
+static int launch_skinny_rows(const LinearArgs& a, const RowPlan& p, hipStream_t s) {
+  LinearArgs b = a;
+  b.wp = a.wr;
+  b.grp_rows = p.grp_rows;
+  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true, true, false, ROWS>), dim3(p.wgs),
+                     dim3(WAVES * 64), 0, s, b);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+bool skinny_rows_supported(int N, int K, int epi, bool norm) {
+  const RowPlan p = skinny_row_plan(N, K, epi);
+  if (!p.ok) return false;
+  if (epi == EPI_SILU) return norm && p.rows == 10 && p.tiles == 4;
+  if (epi == EPI_RESIDUAL) return !norm && p.rows == 10 && p.tiles == 1;
+  return norm && p.rows == 12 && p.tiles == 2;
+}
+
 // Variant choice from tools/gemv_bench.hip on MI355X (profiles/gemv_bench_r01.txt), M = 8; UNR counts k-tile pairs:
 //   w13  (19456x2560, norm, SwiGLU)  8 waves, 1 pair,  2 tiles
 //   wqkv (6144x2560, norm)           8 waves, 1 pair,  2 tiles
@@ -587,6 +681,12 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_skinny: SwiGLU needs N %% 32");
   const int KT = a.K / 32;
   const int ntile = a.N / 16;
+  if (a.wr && a.M <= 8 && !a.wq && !a.scale && skinny_rows_supported(a.N, a.K, a.epi, a.norm_w != nullptr)) {
+    const RowPlan p = skinny_row_plan(a.N, a.K, a.epi);
+    if (a.epi == EPI_SILU) return launch_skinny_rows<8, 1, 4, 10, EPI_SILU, true>(a, p, s);
+    if (a.epi == EPI_RESIDUAL) return launch_skinny_rows<8, 2, 1, 10, EPI_RESIDUAL, false>(a, p, s);
+    return launch_skinny_rows<8, 1, 2, 12, EPI_STORE, true>(a, p, s);
+  }
   if (a.wq && a.M <= 8 && a.K % 64 == 0 && KT >= 32) {
     // int8 stream (tools/gemv_q8_bench.hip, profiles/r02_gemv_q8.txt).  The wave count stays 8 -- the split-K
     // boundaries, hence the result bits, equal the bf16 kernel on the dequantised weights; pairs in flight and tiles

@@ -211,7 +211,13 @@ def _rope_table(n_pos: int, n_elem: int = 64, base: float = 10000.0) -> torch.Te
 class MiDAC:
     """DAC-shaped codec object (encode / from_indices) whose compute lives in libfishmi.so."""
 
-    def __init__(self, config=None, device="cuda:0"):
+    def __init__(self, config=None, device="cuda:0", check_overflow: bool = False):
+        """check_overflow: after every decode-side call in the default fp16-split arithmetic, read the library's sticky
+        overflow flag (one host wait per call) and, if an operand left the fp16 range (|x| >= 65504 -- the reference's
+        fp32 / bf16 arithmetic has no such limit), repeat the call on the fp32 matrix cores.  On by default for
+        `from_checkpoint` (released weights were never run through this path); off for in-memory states."""
+        self.check_overflow = bool(check_overflow)
+        self.overflow_fallbacks = 0
         self.lib = _lib.load()
         self.config = config if isinstance(config, DacConfig) else (DacConfig.from_any(config) if config else DacConfig())
         self.device = torch.device(device)
@@ -306,9 +312,22 @@ class MiDAC:
             check(self.lib.fmi_dac_set_precision(self._h, planes))
             try:
                 check(fn(self._h, *args))
+                if planes == 2 and self.check_overflow and self.fp16_overflowed():
+                    # saturated samples, not NaNs -- but not the reference's either: redo on the fp32 matrix cores
+                    self.overflow_fallbacks += 1
+                    check(self.lib.fmi_dac_set_precision(self._h, 0))
+                    planes = 0
+                    check(fn(self._h, *args))
             finally:
                 if planes != self._planes:
                     check(self.lib.fmi_dac_set_precision(self._h, self._planes))
+
+    def fp16_overflowed(self) -> bool:
+        """Waits for the codec's stream; True if an operand of the fp16-split arithmetic left the fp16 range since the
+        last call of this method (the flag is cleared)."""
+        f = C.c_int(0)
+        check(self.lib.fmi_dac_fp16_overflow(self._h, C.byref(f)))
+        return bool(f.value)
 
     @classmethod
     def from_state_dict(cls, config, state, device="cuda:0") -> "MiDAC":
@@ -324,7 +343,8 @@ class MiDAC:
         if any("generator" in k for k in state):
             state = {k.replace("generator.", ""): v for k, v in state.items() if "generator." in k}
         folded = fold_weight_norm(state)
-        return cls(DacConfig.from_state_dict(folded, **config_overrides), device=device).load_folded_state(folded)
+        return cls(DacConfig.from_state_dict(folded, **config_overrides), device=device,
+                   check_overflow=True).load_folded_state(folded)
 
     # ---- DAC.encode (modded_dac.py:874-923)
     @torch.no_grad()

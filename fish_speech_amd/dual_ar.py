@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import threading
 import json
 import math
 import os
@@ -224,6 +225,10 @@ class MiDualAR:
         self.prefilled_rows = 0                             # bookkeeping for tests / reports
         self.reused_rows = 0
         self._seed_counter = itertools.count()
+        # One generation call at a time per model: slots, workspaces and graphs of a handle are shared state (the
+        # reference serialises LLM work through its single-worker queue, inference.py:748-799).  Entry points that
+        # own a whole request (engine.StreamingTTSEngine.inference) hold this lock for its duration.
+        self.lock = threading.RLock()
         self._dtype_probe = torch.empty(0, dtype=torch.bfloat16, device=self.device)
         self.fixed_temperature = torch.tensor(0.7, device=self.device)
         self.fixed_top_p = torch.tensor(0.7, device=self.device)
@@ -378,6 +383,7 @@ class MiDualAR:
         xs = x.reshape(ncb1, -1).t().to(device=self.device, dtype=torch.int32).contiguous()
         pos0 = 0 if input_pos is None else int(input_pos.reshape(-1)[0].item())
         self._check_tokens(xs)
+        self._cached_prompt.pop(0, None)           # slot 0's K/V are rewritten: a retained prefix is stale now
         ids = self._table(1, torch.int32).view(-1).long()
         live = torch.empty(ids.numel(), dtype=torch.bfloat16, device=self.device)
         hidden = torch.empty(cfg.dim, dtype=torch.bfloat16, device=self.device)
@@ -443,7 +449,12 @@ class MiDualAR:
         already holds are run (fmi_dualar_prefill_resume): bit-identical to running the whole prompt."""
         n = len(slots)
         pos0 = [0] * n
-        if reuse_prefix:   # prefix-KV reuse (generate_long's chunks): skip what the slot's cache already holds
+        # prefix-KV reuse (generate_long's chunks): skip what the slot's cache already holds.  Single-prompt calls only:
+        # the C side picks the GEMV or the tiled GEMM from the TOTAL row count of a call, so in a batch of short
+        # prompts the kernel class of a resumed suffix could differ from what a full prefill of the batch would use
+        # and the documented bit-identity with re-prefill would not hold.
+        reuse_prefix = reuse_prefix and n == 1
+        if reuse_prefix:
             pos0 = [self._reusable_prefix(int(s), p) for s, p in zip(slots, prompts)]
         for s, p0 in zip(slots, pos0):
             if p0 == 0 and self._cached_prompt.pop(int(s), None) is not None:
@@ -558,6 +569,7 @@ class MiDualAR:
         """One frame for one slot = the decode_one_token seam.  x: (S, 1+ncb) int32 on device."""
         ncb1 = self.config.num_codebooks + 1
         self._check_tokens(x)
+        self._cached_prompt.pop(int(slot), None)   # this call rewrites the slot's K/V: a retained prefix is stale now
         out = torch.empty(ncb1, dtype=torch.int32, device=self.device)
         prev = None
         if previous_tokens is not None:

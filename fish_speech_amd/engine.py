@@ -10,6 +10,7 @@ loop and the incremental codec decode of `stream.generate_stream` are interleave
 equals `from_indices` over the codes the offline path generates (tests/test_stream_gpu.py)."""
 from __future__ import annotations
 
+import contextlib
 import io
 import wave
 from dataclasses import dataclass
@@ -67,7 +68,15 @@ class StreamingTTSEngine:
 
     @torch.no_grad()
     def inference(self, req: TTSRequest) -> Iterator[InferenceResult]:
+        """Threading contract: may be called from any number of request threads (the reference's api_server does); the
+        model's lock is held from the first `next()` until the generator finishes or is closed, so requests are served
+        one after the other -- the reference serialises them through its single-worker llama queue.  A consumer that
+        abandons the generator must `close()` it (a `for` loop that breaks does)."""
         model, codec = self.model, self.decoder_model
+        with getattr(model, "lock", None) or contextlib.nullcontext():
+            yield from self._inference_locked(req, model, codec)
+
+    def _inference_locked(self, req: TTSRequest, model, codec) -> Iterator[InferenceResult]:
         sample_rate = codec.sample_rate
         try:
             if req.streaming:
@@ -94,7 +103,7 @@ class StreamingTTSEngine:
                                               max_new_tokens=req.max_new_tokens, first_chunk_frames=req.first_chunk_frames,
                                               chunk_frames=req.chunk_frames, chunk_growth=req.chunk_growth,
                                               max_chunk_frames=req.max_chunk_frames, seeds=seeds, temperature=req.temperature,
-                                              top_p=req.top_p, top_k=req.top_k):
+                                              top_p=req.top_p, top_k=req.top_k, reuse_prefix=True):
                         n = ch.valid_frames[0]
                         if n <= 0:
                             continue
@@ -112,6 +121,13 @@ class StreamingTTSEngine:
                 yield InferenceResult("final", (sample_rate, np.concatenate(segments, axis=0)), None)
         except Exception as e:   # the reference reports worker errors as a result, not as a raise (__init__.py:88-98)
             yield InferenceResult("error", None, e)
+        finally:
+            # every text chunk's prompt repeats the conversation so far: the slot's prefill K/V were kept between
+            # the chunks (prefix-KV reuse, like text2semantic.generate_long) and are dropped with the request
+            try:
+                model.release(0)
+            except Exception:      # noqa: BLE001 -- nothing was prefilled (the request failed before its first chunk)
+                pass
 
 
 def inference_wrapper(req: TTSRequest, engine: StreamingTTSEngine):

@@ -10,6 +10,8 @@ kernels are batch-invariant and the sampler's random stream is keyed by the seed
 equals `generate(model, prompt_i, seed=seed_i)` whatever the arrival order or slot (tests/test_stream_gpu.py)."""
 from __future__ import annotations
 
+import numbers
+
 from typing import List, Optional, Sequence
 
 import torch
@@ -44,7 +46,11 @@ def generate_queue(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_
     (1+ncb, T_i + n_i) like the reference's `generate`.  `max_new_tokens`: one int, or one per utterance."""
     cfg = model.config
     n = len(prompts)
-    per_utt = [int(max_new_tokens)] * n if isinstance(max_new_tokens, int) else [int(m) for m in max_new_tokens]
+    if max_new_tokens is None:                          # None / 0 = no limit, like generate()
+        max_new_tokens = 0
+    per_utt = ([int(max_new_tokens)] * n if isinstance(max_new_tokens, numbers.Integral) or
+               (isinstance(max_new_tokens, torch.Tensor) and max_new_tokens.ndim == 0)
+               else [int(m) if m is not None else 0 for m in max_new_tokens])
     assert len(per_utt) == n
     for p in prompts:
         if p.size(1) >= cfg.max_seq_len:  # inference.py:263-266

@@ -65,12 +65,14 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
                     first_chunk_frames: int = 8, chunk_frames: int = 32, seeds: Optional[Sequence[int]] = None,
                     stop_on_im_end: bool = True, temperature: float = 1.0, top_p: float = 0.9, top_k: int = 30,
                     use_ras: bool = True, timing: Optional[list] = None, chunk_growth: float = 1.0,
-                    max_chunk_frames: int = 256) -> Iterator[StreamChunk]:
+                    max_chunk_frames: int = 256, reuse_prefix: bool = False) -> Iterator[StreamChunk]:
     """Generate a batch of utterances and yield their audio chunk by chunk.
 
     Utterance i's audio is the concatenation over chunks of ``chunk.audio[i, :, :valid_frames[i]*frame_length]``
     and equals ``codec.from_indices(generate_batch(...)[i][1:, T_i:-1])``.  ``timing``: a list that receives the host
-    wall time of every phase per chunk (tools/stream_latency.py --timing)."""
+    wall time of every phase per chunk (tools/stream_latency.py --timing).  ``reuse_prefix`` (one prompt only): keep
+    the slot's K/V when the stream ends and, next time, prefill only the columns past the longest shared prefix
+    (``MiDualAR.prefill``); the caller releases slot 0 when the conversation is over."""
     cfg = model.config
     n = len(prompts)
     for p in prompts:
@@ -85,7 +87,11 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
     slots = list(range(n))
     seeds = list(seeds) if seeds is not None else [model.next_seed() for _ in range(n)]
     samp = [model._sampling(temperature, top_p, top_k, seeds[i], use_ras) for i in range(n)]
-    model.prefill(slots, prompts, mn, samp)            # generates frame 0 of every utterance
+    reuse_prefix = reuse_prefix and n == 1
+    if reuse_prefix:
+        model.prefill(slots, prompts, mn, samp, reuse_prefix=True)   # generates frame 0 of every utterance
+    else:
+        model.prefill(slots, prompts, mn, samp)
     total = max(mn)
     generated = 1
     emitted = 0
@@ -122,5 +128,6 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
             if all(finished):
                 break
     finally:
-        for i in slots:
-            model.release(i)
+        if not reuse_prefix:
+            for i in slots:
+                model.release(i)

@@ -249,6 +249,12 @@ int fmi_dac_weights_ready(fmi_dac* h);
  *   1           bf16 matrix cores, operands and result of every conv / linear rounded to bf16: what the engine's
  *               torch.autocast(bfloat16) computes (fish_speech/inference_engine/__init__.py:179-192). */
 int fmi_dac_set_precision(fmi_dac* h, int planes);
+/* Precision 2 needs every operand inside the fp16 range (|x| < 65504; the reference computes in fp32 / bf16, whose
+ * range is 3e38).  The split saturates outside it -- finite, wrong samples instead of NaNs -- and raises a sticky
+ * device flag.  This call waits for the handle's stream, returns the flag in *overflowed (0 / 1) and clears it; a
+ * caller that sees 1 repeats the decode with fmi_dac_set_precision(h, 0).  fish_speech_amd.dac.MiDAC does so when
+ * constructed with check_overflow=True. */
+int fmi_dac_fp16_overflow(fmi_dac* h, int* overflowed);
 
 /* DAC.from_indices (fish_speech/models/dac/modded_dac.py:925-927): indices int64
  * (B,1+n_codebooks,T) -> audio fp32 (B,1,T*frame_length).  Like the reference

@@ -219,6 +219,125 @@ def make_peaky_state(cfg: DualARConfig, seed: int = 0, emb_gain: float = 1.5, sl
     return {k: v.to(dtype) for k, v in st.items()}
 
 
+# ----------------------------------------------------------------------------- portable (CPU == GPU) weights
+
+
+def _mix32(x: torch.Tensor) -> torch.Tensor:
+    """murmur3 finaliser on 32-bit values carried in int64 tensors (wrap-around multiplies keep their low 32 bits
+    on CPU and GPU alike, so the result is bit-identical on every device)."""
+    m = 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & m
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & m
+    return x ^ (x >> 16)
+
+
+def hash_normal(shape, key: int, std: float, device="cpu", mean: float = 0.0, chunk: int = 1 << 26) -> torch.Tensor:
+    """Counter-based pseudo-normal fp32 tensor that is BIT-IDENTICAL on CPU and GPU: element i gets the sum of four
+    16-bit fields of two murmur-mixed 32-bit words of (key, i) -- integer arithmetic only --, centred and scaled by ONE
+    fp32 multiply (Irwin-Hall with n = 4: variance 4 * 65536^2 / 12).  torch's own generators differ between devices,
+    so fixtures written by the reference on the authoring container's CPU could not otherwise be re-created on the
+    GPU box without minutes of CPU generation for the 4.56 B-parameter S2-Pro shape."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    scale = std / (65536.0 / math.sqrt(3.0))
+    k1 = (key * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF
+    k2 = (key * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF
+    if torch.device(device).type == "cpu":   # same integers through numpy uint32 (wraps natively), 8 threads
+        from concurrent.futures import ThreadPoolExecutor
+
+        out_np = np.empty(n, dtype=np.float32)
+        sc, mu = np.float32(scale), np.float32(mean)
+
+        def mix(x):
+            x ^= x >> np.uint32(16)
+            x *= np.uint32(0x85EBCA6B)
+            x ^= x >> np.uint32(13)
+            x *= np.uint32(0xC2B2AE35)
+            x ^= x >> np.uint32(16)
+            return x
+
+        def work(s):
+            e = min(n, s + (1 << 20))
+            i = np.arange(s, e, dtype=np.uint64).astype(np.uint32)   # n < 2^32
+            a = mix((i * np.uint32(0x27D4EB2F)) ^ np.uint32(k1))
+            b = mix((i * np.uint32(0x165667B1) + np.uint32(0x9E3779B9)) ^ np.uint32(k2))
+            tot = ((a & np.uint32(0xFFFF)) + (a >> np.uint32(16)) + (b & np.uint32(0xFFFF)) + (b >> np.uint32(16))).astype(np.int32) - np.int32(131070)
+            r = tot.astype(np.float32) * sc
+            if mean:
+                r += mu
+            out_np[s:e] = r
+
+        assert n < (1 << 32)
+        with ThreadPoolExecutor(8) as ex:
+            list(ex.map(work, range(0, n, 1 << 20)))
+        return torch.from_numpy(out_np).view(*shape)
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        i = torch.arange(s, e, dtype=torch.int64, device=device)
+        a = _mix32(((i * 0x27D4EB2F) & 0xFFFFFFFF) ^ k1)
+        b = _mix32(((i * 0x165667B1 + 0x9E3779B9) & 0xFFFFFFFF) ^ k2)
+        tot = (a & 0xFFFF) + (a >> 16) + (b & 0xFFFF) + (b >> 16) - 131070
+        out[s:e] = tot.to(torch.float32) * scale
+        if mean:
+            out[s:e] += mean
+    return out.view(*shape)
+
+
+def make_peaky_state_hash(cfg: DualARConfig, seed: int = 0, emb_gain: float = 1.5, slow_gain: float = 2.0,
+                          fast_gain: float = 1.5, hot=(1.0,), hot_every: int = 1, eos_code: Optional[int] = None,
+                          fast_emb_gain: Optional[float] = None, pair_cycles: bool = False, device="cpu",
+                          dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """`make_peaky_state` on `hash_normal` weights: the same construction (see there), but every tensor is a pure
+    function of (seed, tensor name, element index) computed with integer arithmetic, so the GPU box re-creates on the
+    device -- in seconds, bit for bit -- the 4.56 B-parameter model the reference ran on the authoring container's CPU
+    (oracle/gen_golden_s2.py).  The permutations come from the CPU generator (portable).  `fast_emb_gain` scales the
+    fast embeddings separately (default: emb_gain): behind 4 + 36 layers the two peaks need different gains.
+    `pair_cycles`: the first successor of code a is a ^ 1 instead of a random permutation -- with 4096 codes a random
+    permutation never revisits a token inside the 10-frame RAS window; 2-cycles make RAS fire on every frame (the
+    high-temperature draw replaces the normal one, inference.py:118-141) until a code with extra candidates escapes."""
+    import zlib
+
+    def base(name, shape, to=dtype):
+        key = (zlib.crc32(name.encode()) ^ (seed * 0x01000193)) & 0xFFFFFFFF
+        if len(shape) == 1:
+            return hash_normal(shape, key, 0.1, device, mean=1.0).to(to)
+        return hash_normal(shape, key, 0.02, device).to(to)
+
+    special = ("embeddings.weight", "codebook_embeddings.weight", "fast_embeddings.weight", "fast_output.weight")
+    shapes = state_shapes(cfg)
+    st = {k: base(k, s) for k, s in shapes.items() if k not in special}
+    g = torch.Generator().manual_seed(seed * 7919 + 13)
+    cbs = cfg.codebook_size
+    assert cfg.semantic_end_id - cfg.semantic_begin_id + 1 == cbs
+    E = base("embeddings.weight", shapes["embeddings.weight"], torch.float32) * emb_gain
+    CB = base("codebook_embeddings.weight", shapes["codebook_embeddings.weight"], torch.float32)
+    rows = torch.zeros(cbs, cfg.dim, device=device)
+    for i, h in enumerate(hot):
+        perm = torch.randperm(cbs, generator=g).to(device)
+        if i == 0 and pair_cycles:
+            perm = torch.arange(cbs, device=device) ^ 1
+        r = h * E[cfg.semantic_begin_id + perm]
+        if i > 0:
+            r[(torch.arange(cbs) % hot_every != 0).to(device)] = 0
+        rows += r
+    if eos_code is not None:
+        rows[eos_code] = hot[0] * E[cfg.im_end_id]
+    CB[:cbs] = slow_gain * rows
+    fe = base("fast_embeddings.weight", shapes["fast_embeddings.weight"], torch.float32)
+    fo = base("fast_output.weight", shapes["fast_output.weight"], torch.float32)
+    fperm = torch.randperm(cbs, generator=g).to(device)
+    fo[fperm] = fast_gain * fe
+    st["embeddings.weight"] = E.to(dtype)
+    st["codebook_embeddings.weight"] = CB.to(dtype)
+    st["fast_embeddings.weight"] = (fe * (emb_gain if fast_emb_gain is None else fast_emb_gain)).to(dtype)
+    st["fast_output.weight"] = fo.to(dtype)
+    return {k: st[k] for k in shapes}
+
+
 # ----------------------------------------------------------------------------- primitives
 
 

@@ -1,0 +1,148 @@
+"""Golden fixtures at the BASELINE model width: the UNMODIFIED reference's generate() on the S2-Pro-shaped 4.56 B
+parameter model (authoring container only: needs /root/reference, ~25 GB of RAM and a few minutes per case).
+`python -m oracle.gen_golden_s2 [case ...]`.
+
+Weights: `oracle.dual_ar.make_peaky_state_hash` -- every tensor a pure integer-arithmetic function of (seed, tensor
+name, element index), so the GPU box re-creates the very same bf16 model on the device in seconds (torch's CPU and GPU
+generators differ, which is why the earlier full-width tests could only compare against an oracle run on the box).
+Gains: at 36 layers the residual stream is dominated by the layers' own outputs (rms ~0.6 per layer against 0.03 for
+an embedding row), so the codebook-0 row that points at the successor needs slow_gain ~200 for the successor's logit to
+stand ~10 sigma above the other 4096 (measured: slow_gain 100 -> top logit 8 against a noise maximum of 6; 300 -> 24),
+and the fast embeddings need x30.
+
+What is written (tests/golden/dualar_s2_*.npz, a few KB each): the prompt, the token matrix generate() returned, the
+per-frame minimum decision margin measured on the reference's own logits, the sampling parameters and the weight
+recipe.  Asserted before writing: the oracle reproduces the reference run bit for bit on this machine; greedy cases
+have >= MIN_MARGIN bf16 steps at every decision; the sampled case is invariant under NOISE_ULPS steps of logit noise
+at every decision, draws non-top-1 tokens and fires RAS."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import dual_ar as O
+from .gen_golden import OUT, _ref_generate, live_ids
+from .refload import FakeTokenizer, add_reference_to_path
+from . import refload
+
+MIN_MARGIN = 16.0
+NOISE_ULPS = 2
+
+GREEDY_STATE = dict(seed=1, emb_gain=1.5, slow_gain=200.0, fast_gain=1.0, fast_emb_gain=30.0)
+SAMPLED_STATE = dict(seed=2, emb_gain=1.5, slow_gain=200.0, fast_gain=1.0, fast_emb_gain=30.0, hot=(1.0, 0.95, 0.93),
+                     hot_every=8, pair_cycles=True)
+
+CASES = {
+    # name: (state kwargs, prompt (T, n_semantic, candidate seeds), frames, (temperature, top_p, top_k), candidate uniform seeds)
+    "s2_plain": (GREEDY_STATE, (200, 0, range(1, 40)), 64, (0.7, 0.7, 1), range(1234, 1260)),
+    "s2_clone": (GREEDY_STATE, (200, 100, range(1, 8)), 64, (0.7, 0.7, 1), range(1234, 1260)),
+    "s2_sampled": (SAMPLED_STATE, (200, 60, range(1, 8)), 64, (0.7, 0.9, 30), range(1, 200)),
+}
+
+
+def build_reference_meta(cfg, state):
+    """The reference DualARTransformer over the given tensors without the 18 GB fp32 random init of its constructor:
+    built on the meta device, parameters assigned from `state`, the two non-persistent buffers rebuilt by the
+    reference's own functions."""
+    add_reference_to_path()
+    from fish_speech.models.text2semantic import llama as RL
+
+    args = RL.DualARModelArgs(**cfg.reference_kwargs())
+    with torch.device("meta"):
+        model = RL.DualARTransformer(args)
+    missing, unexpected = model.load_state_dict(state, strict=False, assign=True)
+    assert not unexpected, unexpected
+    assert all(m in ("freqs_cis", "causal_mask", "fast_freqs_cis") for m in missing), missing
+    model.register_buffer("freqs_cis", RL.precompute_freqs_cis(args.max_seq_len, args.head_dim, args.rope_base), persistent=False)
+    model.register_buffer("causal_mask", torch.tril(torch.ones(args.max_seq_len, args.max_seq_len, dtype=torch.bool)), persistent=False)
+    model.register_buffer("fast_freqs_cis", RL.precompute_freqs_cis(args.num_codebooks, args.fast_head_dim, args.rope_base), persistent=False)
+    for n, p in model.named_parameters():
+        assert p.device.type == "cpu" and p.dtype == torch.bfloat16, n
+    model = model.eval()
+    model.tokenizer = FakeTokenizer(cfg.im_end_id)
+    model._cache_setup_done = False
+    return model
+
+
+def main(which):
+    from .search_golden import sampled_run_is_robust
+
+    torch.set_num_threads(8)
+    cfg = O.s2_pro_shaped_config(max_seq_len=512)
+    ids = live_ids(cfg)
+    states = {}
+    orig_build = refload.build_reference_dual_ar
+    import oracle.gen_golden as GG
+
+    for name in which:
+        skw, (T, nsem, pseeds), frames, (temp, top_p, top_k), useeds = CASES[name]
+        key = json.dumps(skw, sort_keys=True)
+        if key not in states:
+            states.clear()
+            t0 = time.time()
+            states[key] = O.make_peaky_state_hash(cfg, **skw)
+            print(f"{name}: state built in {time.time() - t0:.0f}s", flush=True)
+        state = states[key]
+        orc = O.DualAROracle(cfg, state)
+        found = None
+        # the ORACLE (0.5 s/frame) searches the prompt / uniform seeds; the reference then re-runs the winner
+        for pseed in pseeds:
+            prompt = O.make_prompt(cfg, T, seed=pseed, n_semantic=nsem)
+            for useed in useeds:
+                orc.trace = {}
+                t0 = time.time()
+                y = O.generate(orc, prompt, frames, temp, top_p, top_k, uniform_fn=O.FmiUniform(useed, 0),
+                               stop_on_im_end=False)
+                slow_full = torch.stack(orc.trace["slow_logits"])
+                fast = torch.stack([torch.stack(f) for f in orc.trace["fast_logits"]])
+                margins = O.greedy_frame_margins(cfg, slow_full[:, ids], fast)
+                n0 = int((y[0, T:] == 0).sum())
+                if top_k == 1:
+                    ok = float(margins.min()) >= MIN_MARGIN
+                    note = f"min margin {float(margins.min()):.1f}, u==0 slow tokens {n0}"
+                else:
+                    rtr = {"slow_logits": list(slow_full), "fast_logits": [list(f) for f in fast]}
+                    rob, nt, ras = sampled_run_is_robust(cfg, y, rtr, T, temp, top_p, top_k, useed, ulps=NOISE_ULPS)
+                    ok = rob and nt >= 3 and ras >= 8
+                    note = f"robust {rob}, non-top-1 {nt}, RAS {ras}, u==0 slow tokens {n0}"
+                print(f"  {name}: prompt seed {pseed} uniform seed {useed}: {note} ({time.time() - t0:.0f}s)", flush=True)
+                if ok:
+                    found = (pseed, useed, prompt, y, margins, note)
+                    break
+                if top_k == 1 and float(margins[0]) < MIN_MARGIN:
+                    break   # the first decision depends on the prompt only: next prompt
+            if found:
+                break
+        assert found, name
+        pseed, useed, prompt, y, margins, note = found
+        # the UNMODIFIED reference on the same tensors
+        GG.build_reference_dual_ar = build_reference_meta
+        try:
+            t0 = time.time()
+            tr = {}
+            tokens = _ref_generate(cfg, state, prompt, frames, top_k, O.FmiUniform(seed=useed, stream=0), trace=tr,
+                                   temperature=temp, top_p=top_p)
+            print(f"  {name}: reference generate() {time.time() - t0:.0f}s", flush=True)
+        finally:
+            GG.build_reference_dual_ar = orig_build
+        # generate() stops at <|im_end|>; the cases are chosen not to contain one
+        assert tokens.shape == y.shape and torch.equal(tokens, y), f"{name}: oracle != reference"
+        slow_ref = torch.stack(tr["slow_logits"])[:, ids]
+        fast_ref = torch.stack([torch.stack(f) for f in tr["fast_logits"]])
+        m_ref = O.greedy_frame_margins(cfg, slow_ref, fast_ref)
+        assert torch.equal(m_ref, margins), "the reference's own logits give other margins than the oracle's"
+        np.savez_compressed(
+            os.path.join(OUT, f"dualar_{name}.npz"), prompt=prompt.numpy(), tokens=tokens.numpy(),
+            state_kind="peaky_hash", state_kwargs=json.dumps(skw), max_new=frames, uniform_seed=useed,
+            prompt_seed=pseed, temperature=temp, top_p=top_p, top_k=top_k, greedy_margins_ulps=margins.numpy(),
+            note=note)
+        print(f"{name}: written; {note}", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or list(CASES))

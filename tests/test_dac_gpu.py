@@ -116,6 +116,40 @@ def test_causal_prefix_and_batch_invariance_at_10s(full):
     assert float((part[0, 0] - both[0, 0, : 100 * 2048]).abs().max()) <= 2e-5
 
 
+def test_baseline_shape_from_indices_2x215_and_inside_a_batch_of_8_vs_oracle(full):
+    """The BASELINE decode shape against the oracle: two 215-frame utterances (10 s each,
+    440 320 samples) decoded by the CPU oracle; the HIP codec must match them (RMS <= 1e-4) decoded as a batch of 2
+    AND as rows 5 and 2 of the benchmark's batch of 8 x 215 frames (grids of up to 3440 work-groups, the codec
+    transformer's linears at 1720 columns), where they must also equal their batch-of-2 samples bit for bit."""
+    cfg, state, codec = full
+    codes = D.make_codes(cfg, 8, 215, seed=31)
+    want = D.DacOracle(cfg, state).from_indices(codes[[5, 2]].clone())
+    pair = codec.from_indices(codes[[5, 2]].clone().to(DEV)).cpu()
+    eight = codec.from_indices(codes.clone().to(DEV)).cpu()
+    assert eight.shape == (8, 1, 215 * 2048) and bool(torch.isfinite(eight).all())
+    sig = float(want.pow(2).mean().sqrt())
+    e2, e8 = rms(pair, want), rms(eight[[5, 2]], want)
+    print(f"2 x 215 frames vs oracle: rms {e2:.3e} (batch of 2), {e8:.3e} (inside the batch of 8); signal rms {sig:.4f}")
+    assert e2 <= 1e-4 and e8 <= 1e-4
+    assert torch.equal(eight[[5, 2]], pair)
+
+
+def test_encode_10s_clip_bit_exact_vs_oracle(full):
+    """encode() of a 10 s clip (441 000 samples -> 216 frames): every index equals the oracle's."""
+    cfg, state, codec = full
+    n = 10 * cfg.sample_rate
+    g = torch.Generator().manual_seed(41)
+    t = torch.arange(n) / cfg.sample_rate
+    audio = (0.25 * torch.sin(2 * np.pi * 180 * t) + 0.1 * torch.sin(2 * np.pi * 1330 * t + 1.0) +
+             0.03 * torch.randn(n, generator=g)).view(1, 1, n)
+    codes, lens = codec.encode(audio.to(DEV), torch.tensor([n], device=DEV))
+    want, wl = D.DacOracle(cfg, state).encode(audio, torch.tensor([n]))
+    assert lens.tolist() == wl.tolist() == [216] and codes.shape == (1, 10, 216)
+    agree = float((codes.cpu() == want).float().mean())
+    print("10 s clip: code agreement with the oracle", agree)
+    assert torch.equal(codes.cpu(), want)
+
+
 def test_config0_3s_clip_encode_decode_vs_oracle(full):
     """BASELINE configs[0]: encode -> decode of one 3 s 44.1 kHz mono clip (132 300 samples, padded to
     133 120 = 65 frames), yaml-sized codec, against the CPU oracle: codes bit-exact, waveform RMS <= 1e-4;

@@ -41,8 +41,10 @@ class StubDualAR:
     def natural_len(seed):
         return 4 + (13 * seed) % 37
 
-    def prefill(self, slots, prompts, max_new, samp):
+    def prefill(self, slots, prompts, max_new, samp, reuse_prefix=False):
         for s, m, seed in zip(slots, max_new, samp):
+            if reuse_prefix:                     # the slot was kept by the previous chunk of the conversation
+                self.slots.pop(s, None)
             assert s not in self.slots
             self.slots[s] = dict(seed=seed, limit=min(m, self.natural_len(seed)), eos=self.natural_len(seed) <= m, n=1)
 

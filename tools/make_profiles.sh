@@ -1,0 +1,43 @@
+#!/bin/bash
+# Regenerate EVERY profiles/rNN_* summary from the current binary on the GPU box (one command):
+#   gpurun -- 'bash tools/make_profiles.sh r03'
+# writes gpurun_out/profiles_<tag>/; copy that directory's files into profiles/ afterwards.
+# Kernel timings (--kernel-trace --stats) and PMC counters (--pmc) are collected in SEPARATE rocprofv3 runs.
+set -u
+TAG=${1:-r03}
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+OUT=gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+W=/tmp/prof_$TAG
+rm -rf "$W"; mkdir -p "$W"
+HEAD=$(git rev-parse --short HEAD 2>/dev/null || echo "snapshot")
+SHA=$(sha1sum fish_speech_amd/libfishmi.so | cut -c1-12)
+
+run_stats() {  # name, header, command...
+  local name=$1 hdr=$2; shift 2
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$W/$name" -o "$name" -- "$@" ) > "$OUT/${name}_run.log" 2>&1
+  local db; db=$(find "$W/$name" -name '*_results.db' | head -1)
+  { echo "# $hdr"; echo "# libfishmi.so sha1 $SHA, tree $HEAD"; grep -h "decode_frame_avg\|planes=\|prefill of 8\|encode B" "$OUT/${name}_run.log" | sed 's/^/# /' | cut -c1-400;
+    python "$PWD/tools/rocpd_summary.py" "$db"; } > "$OUT/${TAG}_kernels_${name}.txt" 2>&1
+}
+
+R=$PWD
+run_stats step "python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline under rocprofv3 --kernel-trace --stats" \
+  python "$R/bench.py" --steps 2 --warmup 1 --no-extras --no-cpu-baseline
+run_stats codec "tools/codec_bench.py (B=8, T=215, fp16-split default + encode) under rocprofv3 --kernel-trace --stats" \
+  env PLANES=2 python "$R/tools/codec_bench.py"
+run_stats prefill "tools/prefill_bench.py 200 2048 (S2-Pro shape, 8 prompts) under rocprofv3 --kernel-trace --stats" \
+  python "$R/tools/prefill_bench.py" 200 2048
+
+# HBM traffic of the decode frame: PMC pass on its own (12 frames: 1 prefill frame + 11 graph-replayed decode frames)
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$W/pmc" -o p -- \
+    python "$R/bench.py" --frames 12 --steps 1 --warmup 0 --no-codec --no-extras --no-cpu-baseline ) > "$OUT/pmc_run.log" 2>&1
+CSV=$(find "$W/pmc" -name '*counter_collection.csv' | head -1)
+{ echo "# rocprofv3 --pmc FETCH_SIZE --kernel-trace over bench.py --frames 12 --steps 1 --warmup 0 --no-codec (libfishmi.so sha1 $SHA, tree $HEAD)";
+  python tools/pmc_traffic.py "$CSV" 12 "$OUT/pmc_traffic.json"; } > "$OUT/${TAG}_pmc_fetch_decode.txt" 2>&1
+
+# timing-only runs (no profiler): streaming breakdown + latency
+python tools/stream_breakdown.py > "$OUT/${TAG}_stream_breakdown.txt" 2>&1
+python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt" 2>&1
+ls -la "$OUT"

@@ -2,13 +2,15 @@
 """Per-frame HBM read traffic of the decode frame from a rocprofv3 `--pmc FETCH_SIZE --kernel-trace
 --output-format csv` pass (collected separately from the timing runs, as MI355X_MICROARCH.md prescribes).
 FETCH_SIZE is in KiB and, on gfx950, reports exactly half of the bytes of wide coalesced streaming reads,
-so it is doubled.  usage: python tools/pmc_traffic.py <counter_collection.csv> <n_frames_of_that_run>"""
+so it is doubled.  usage: python tools/pmc_traffic.py <counter_collection.csv> <n_frames_of_that_run> [out.json]
+With out.json the per-frame figure is also written as the small JSON bench.py reads (profiles/pmc_traffic.json)."""
 import collections
 import csv
+import json
 import sys
 
 
-def main(path, n_frames):
+def main(path, n_frames, out_json=None):
     agg = collections.defaultdict(lambda: [0, 0.0])
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == "FETCH_SIZE"]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
@@ -43,7 +45,15 @@ def main(path, n_frames):
     print(f"\nHBM bytes fetched by the decode-frame kernels: {frame_bytes / 1e9:.3f} GB over the run "
           f"= {frame_bytes / (n_decode + 0.52) / 1e9:.3f} GB per decode frame "
           f"(prefill-frame tail counted as 0.52 frame: the fast chain and the heads of a frame)")
+    if out_json:
+        with open(out_json, "w") as f:
+            json.dump({"bytes_per_decode_frame": round(frame_bytes / (n_decode + 0.52)), "batch": 8, "frames_in_pass": n_frames,
+                       "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace over `bench.py --frames %d --steps 1 --warmup 0 "
+                                 "--no-codec --no-extras --no-cpu-baseline` (tools/make_profiles.sh), summed over the decode-frame "
+                                 "kernels by tools/pmc_traffic.py: KiB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)" % n_frames},
+                      f, indent=1)
+            f.write("\n")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]))
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else None)
