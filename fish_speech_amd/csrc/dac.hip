@@ -125,14 +125,20 @@ struct fmi_dac {
   std::mutex mu;
   std::vector<ConvW> plane_jobs;
   // quantizer-side state of an incremental (streaming) decode: fmi_dac_decode_tail_cached
-  struct {
+  struct StreamState {
     int B = 0, T = 0, cap = 0;            // utterances, frames covered so far, frame capacity of the buffers
     int64_t id = 0;                       // the caller's stream id the state belongs to
     int planes = -1;                      // arithmetic (fmi_dac_set_precision) the state was computed with
     std::vector<float*> qkv;              // per post-transformer layer: roped q|k|v of every frame [B][3C][cap]
     float* tf_out = nullptr;              // transformer output [B][C][cap]
     float* z = nullptr;                   // upsampled latents [B][latent][4 cap]
-  } st;
+    uint64_t used = 0;                    // LRU stamp
+  } st;                                   // the state the kernels of the current call work on
+  // states of OTHER streams that are still open (a serving loop interleaves the chunks of several utterances, each
+  // with its own stream id): parked here between their calls, least recently used one dropped beyond MAX_PARKED
+  std::vector<StreamState> parked;
+  uint64_t st_clock = 0;
+  static constexpr size_t MAX_PARKED = 15;
 };
 
 namespace {
@@ -608,14 +614,62 @@ int run_quantizer_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float**
   return FMI_OK;
 }
 
-void free_stream_state(fmi_dac* h) {
-  for (float* p : h->st.qkv)
+void free_one_state(fmi_dac::StreamState& st) {
+  for (float* p : st.qkv)
     if (p) hipFree(p);
-  h->st.qkv.clear();
-  if (h->st.tf_out) hipFree(h->st.tf_out);
-  if (h->st.z) hipFree(h->st.z);
-  h->st.tf_out = h->st.z = nullptr;
-  h->st.B = h->st.T = h->st.cap = 0;
+  st.qkv.clear();
+  if (st.tf_out) hipFree(st.tf_out);
+  if (st.z) hipFree(st.z);
+  st.tf_out = st.z = nullptr;
+  st.B = st.T = st.cap = 0;
+  st.id = 0;
+}
+
+void free_stream_state(fmi_dac* h) { free_one_state(h->st); }
+
+void free_all_stream_states(fmi_dac* h) {
+  free_one_state(h->st);
+  for (auto& p : h->parked) free_one_state(p);
+  h->parked.clear();
+}
+
+// Make h->st the state of `stream_id`: the current one is parked if it belongs to another open stream, the wanted
+// one is taken back from the parked set if it is there (else h->st stays empty and the call starts from frame 0).
+int select_stream_state(fmi_dac* h, int64_t stream_id) {
+  h->st.used = ++h->st_clock;
+  if (h->st.id == stream_id || h->st.T == 0) {
+    if (h->st.id != stream_id) {          // an empty / invalid state: reuse its buffers only for the same stream
+      for (size_t i = 0; i < h->parked.size(); ++i)
+        if (h->parked[i].id == stream_id) {
+          FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+          free_one_state(h->st);
+          h->st = h->parked[i];
+          h->parked.erase(h->parked.begin() + i);
+          h->st.used = h->st_clock;
+          break;
+        }
+    }
+    return FMI_OK;
+  }
+  fmi_dac::StreamState mine;
+  for (size_t i = 0; i < h->parked.size(); ++i)
+    if (h->parked[i].id == stream_id) {
+      mine = h->parked[i];
+      h->parked.erase(h->parked.begin() + i);
+      break;
+    }
+  h->parked.push_back(h->st);
+  h->st = mine;
+  h->st.used = h->st_clock;
+  if (h->parked.size() > fmi_dac::MAX_PARKED) {
+    size_t lru = 0;
+    for (size_t i = 1; i < h->parked.size(); ++i)
+      if (h->parked[i].used < h->parked[lru].used) lru = i;
+    FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+    free_one_state(h->parked[lru]);
+    h->parked.erase(h->parked.begin() + lru);
+  }
+  return FMI_OK;
 }
 
 // frames of transformer output to the left of a frame that its upsampled latents depend on (two stages of
@@ -738,7 +792,7 @@ void fmi_dac_destroy(fmi_dac* h) {
   if (h->staging) hipFree(h->staging);
   for (auto p : h->pbuf)
     if (p) hipFree(p);
-  free_stream_state(h);
+  free_all_stream_states(h);
   hipEventDestroy(h->ev_in);
   hipEventDestroy(h->ev_out);
   hipStreamDestroy(h->stream);
@@ -923,7 +977,8 @@ int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, i
   FMI_CHECK(sync_in(h, stream));
   h->cur_planes = h->decode_planes;
   hipStream_t s = h->stream;
-  // continue the state of the previous call, or start over (first call, other batch, a gap, buffers too small)
+  // continue the state of this stream's previous call, or start over (first call, other batch, a gap, buffers too small)
+  FMI_CHECK(select_stream_state(h, stream_id));
   int from = t0;
   if (!(h->st.B == B && h->st.id == stream_id && h->st.planes == h->cur_planes && h->st.T == t0 && t0 > 0 &&
         T <= h->st.cap)) {
@@ -959,7 +1014,7 @@ int fmi_dac_stream_reset(fmi_dac* h) {
   if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h, "null handle");
   FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
-  free_stream_state(h);
+  free_all_stream_states(h);
   return FMI_OK;
 }
 

@@ -27,7 +27,7 @@ struct LayerW {
   bf16_t *s_wqkv = nullptr, *s_wo = nullptr, *s_w13 = nullptr, *s_w2 = nullptr;
   // row-balanced decode copies (outside the arena, derived on every rank after the weights are in place):
   // streamed by the M <= 8 decode GEMV instead of the 16-row tiles where those leave CUs idle (skinny_row_plan)
-  bf16_t *r_wqkv = nullptr, *r_wo = nullptr, *r_w13 = nullptr, *r_w2 = nullptr;
+  bf16_t *r_wqkv = nullptr, *r_wo = nullptr, *r_w2 = nullptr;   // (w1|w3 keeps its 16-row tiles: skinny_row_plan)
 };
 
 struct Dims {
@@ -238,7 +238,7 @@ int invalidate_derived(fmi_dualar* h) {
   for (void* p : h->row_copies) hipFree(p);
   h->row_copies.clear();
   for (auto* LL : {&h->L, &h->FL})
-    for (auto& w : *LL) w.r_wqkv = w.r_wo = w.r_w13 = w.r_w2 = nullptr;
+    for (auto& w : *LL) w.r_wqkv = w.r_wo = w.r_w2 = nullptr;
   if (h->qkv0_tab) hipFree(h->qkv0_tab);
   if (h->qkv0_pre) hipFree(h->qkv0_pre);
   h->qkv0_tab = h->qkv0_pre = nullptr;
@@ -318,7 +318,7 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
     h->launches += 2;
   }
   FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo, w.r_wo));
-  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13, w.r_w13));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, rows, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
   FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, rows, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2, w.r_w2));
   return FMI_OK;
 }
@@ -339,7 +339,7 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
   h->launches += 1;
   if (kv_only) return FMI_OK;  // only this layer's K/V at `pos` were needed
   FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo, w.r_wo));
-  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13, w.r_w13));
+  FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
   FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2, w.r_w2));
   return FMI_OK;
 }
@@ -420,7 +420,7 @@ int decode_frame(fmi_dualar* h, int B, hipStream_t s, bool head_only = false) {
 // Row-balanced decode copies of the projection matrices whose 16-row tiling leaves CUs idle at the decode shapes
 // (dualar_kernels.h: skinny_row_plan): derived from the packed arena once the weights are in place, on every rank
 // (they are a permutation of arena bytes, so they do not travel with the broadcast).  FMI_NO_ROWS=1 keeps the 16-row
-// tiles (A/B runs).  Costs one extra copy of the layer matrices in HBM (9.1 GB at the S2-Pro shape, of 288 GB).
+// tiles (A/B runs).  Costs one extra copy of the layer matrices in HBM (4.1 GB at the S2-Pro shape, of 288 GB).
 int ensure_row_copies(fmi_dualar* h) {
   if (h->rows_tried || !h->ready) return FMI_OK;
   h->rows_tried = true;
@@ -440,7 +440,6 @@ int ensure_row_copies(fmi_dualar* h) {
   auto layer = [&](LayerW& w, const Dims& d) -> int {
     FMI_CHECK(derive(w.wqkv, &w.r_wqkv, d.qkv, d.dim, EPI_STORE, true));
     FMI_CHECK(derive(w.wo, &w.r_wo, d.dim, d.H * d.D, EPI_RESIDUAL, false));
-    FMI_CHECK(derive(w.w13, &w.r_w13, 2 * d.ffn, d.dim, EPI_SILU, true));
     return derive(w.w2, &w.r_w2, d.dim, d.ffn, EPI_RESIDUAL, false);
   };
   for (auto& w : h->L) FMI_CHECK(layer(w, h->slow));
@@ -1234,7 +1233,8 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
   a.wp = packed; a.x = (const bf16_t*)x_dev; a.ldx = K; a.norm_w = (const bf16_t*)norm_w_dev; a.eps = eps;
   a.res = (const bf16_t*)residual_dev; a.ldr = n_out; a.out = (bf16_t*)out_dev; a.ldo = n_out; a.M = M; a.N = N;
   a.K = K; a.epi = epilogue;
-  // 2: tiled (LDS-staged), 5: tiled, operands straight from L2, 6: skinny on the row-balanced copy (must exist)
+  // 2: tiled (default variant), 5: tiled, operands straight from L2, 6: skinny on the row-balanced copy (must exist),
+  // 7: tiled, LDS-staged 4-wave kernel, 8: tiled, LDS-staged wave-specialised kernel
   const bool skinny = force_path == 1 || force_path == 6 || (force_path == 0 && M <= 16);
   bf16_t* rowcopy = nullptr;
   if (rc == FMI_OK && force_path == 6) {
@@ -1257,7 +1257,7 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
         a.x = xn;
         a.norm_w = nullptr;
       }
-      if (rc == FMI_OK) rc = launch_linear_tiled(a, s, force_path == 5);
+      if (rc == FMI_OK) rc = launch_linear_tiled(a, s, force_path == 5, force_path == 7 ? 1 : force_path == 8 ? 2 : 0);
     }
   }
   hipStreamSynchronize(s);

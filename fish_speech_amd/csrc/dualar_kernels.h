@@ -62,26 +62,27 @@ struct LinearArgs {
   const bf16_t* scale;
   const int8_t* wq;
   // row-balanced decode copy of `wp` (launch_repack_rows; nullptr = none): streamed instead of `wp` by the M <= 8
-  // decode GEMV, one work-group per CU-sized share of the rows.  grp_rows: SwiGLU only, gate rows per work-group.
+  // decode GEMV, one work-group per CU-sized share of the rows.
   const bf16_t* wr;
-  int grp_rows;
 };
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s);  // M <= 16
 
 // Row-balanced decode geometry of an (N, K) linear on the 256-CU part: `rows` weight rows per tile (< 16 when the
-// 16-row tiling leaves CUs idle), `tiles` tiles per work-group, `wgs` work-groups, `grp_rows` (SwiGLU: gate rows per
-// work-group, the last tile pair zero-padded).  ok == false: the 16-row layout is already balanced or the shape has
-// no balanced tiling; the decode GEMV then streams the 16-row tiles.
+// 16-row tiling leaves CUs idle), `tiles` tiles per work-group, `wgs` work-groups.  ok == false: the 16-row layout is
+// already balanced, the shape has no balanced tiling, or balancing was measured not to pay (SwiGLU pairs); the decode
+// GEMV then streams the 16-row tiles.
 struct RowPlan {
   bool ok;
-  int rows, tiles, wgs, grp_rows;
+  int rows, tiles, wgs;
   int64_t elems;   // bf16 elements of the row-balanced copy (wgs * tiles * rows * K)
 };
 RowPlan skinny_row_plan(int N, int K, int epi);
 bool skinny_rows_supported(int N, int K, int epi, bool norm);   // a row-balanced kernel variant exists for the shape
 // 16-row packed tiles (launch_pack_weight, with its SwiGLU interleave) -> the row-balanced copy of `plan`
 int launch_repack_rows(const bf16_t* packed16, bf16_t* dst, int N, int K, int epi, const RowPlan& plan, hipStream_t s);
-int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct = false);  // any M, no fused norm
+// any M, no fused norm.  variant: 0 = default (FMI_GEMM env: d / l / w, else the built-in default), 1 = LDS-staged
+// 4-wave kernel, 2 = LDS-staged wave-specialised kernel; force_direct: operands straight from L2.  All bit-identical.
+int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct = false, int variant = 0);
 int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf16_t* out, int ldo,
                         int M, int K, hipStream_t s, bf16_t* out2 = nullptr);
 

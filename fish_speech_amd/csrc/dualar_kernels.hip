@@ -76,30 +76,24 @@ int launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int interle
 // [tile][K/32][4 lane groups][ROWS rows][8]: tile t, k-tile j, lane group kg, row b holds the 8 weights the 16-row
 // layout keeps at (row, k-tile j, lane group kg) -- same k permutation, so the activation operand logic is shared.
 RowPlan skinny_row_plan(int N, int K, int epi) {
-  RowPlan p{false, 16, 1, 0, 0, 0};
+  RowPlan p{false, 16, 1, 0, 0};
   constexpr int CUS = 256;
   if ((K % 64) != 0 || K < 1024) return p;   // paired k-tiles only; tiny test models keep the 16-row tiles
-  if (epi == EPI_SILU) {
-    const int half = N / 2;
-    if (N % 2 || half % (2 * CUS) != 0) return p;
-    const int g = half / (2 * CUS);          // gate rows per work-group, two work-groups per CU
-    if (g < 1 || g > 32 || g % 16 == 0) return p;
-    const int pairs = (g + 15) / 16, rows = (g + pairs - 1) / pairs;
-    p = {true, rows, 2 * pairs, 2 * CUS, g, 0};
-  } else {
-    if (N % CUS != 0) return p;
-    const int per = N / CUS;                 // rows per CU
-    if (per < 1 || per > 32 || per % 16 == 0) return p;
-    const int tiles = (per + 15) / 16;
-    if (per % tiles != 0) return p;
-    p = {true, per / tiles, tiles, CUS, 0, 0};
-  }
+  // w1|w3 (SwiGLU, N = 2 x 9728: 608 work-groups = 2.375 per CU) stays on the 16-row tiles: 19 gate + 19 up rows per
+  // work-group x 512 work-groups (two zero-padded 10-row tile pairs, +5 % bytes) measured 21.65 us against 20.9-22.0
+  // (profiles/r03_gemv_rows_bench.txt) -- a launch that already streams at 4.7 TB/s is not occupancy-bound
+  if (epi == EPI_SILU || N % CUS != 0) return p;
+  const int per = N / CUS;                   // rows per CU
+  if (per < 1 || per > 32 || per % 16 == 0) return p;
+  const int tiles = (per + 15) / 16;
+  if (per % tiles != 0) return p;
+  p = {true, per / tiles, tiles, CUS, 0};
   p.elems = (int64_t)p.wgs * p.tiles * p.rows * K;
   return p;
 }
 
-__global__ void repack_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K, int silu,
-                                   int rows, int tiles, int grp_rows, int64_t total) {
+__global__ void repack_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K, int rows,
+                                   int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 16-byte chunk of dst
   if (idx >= total) return;
   const int KT = K >> 5;
@@ -107,19 +101,9 @@ __global__ void repack_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __res
   const int kg = (int)((idx / rows) & 3);
   const int j = (int)((idx / (4 * rows)) % KT);
   const int tile = (int)(idx / ((int64_t)4 * rows * KT));
-  int nd = -1;                                                          // row of the 16-row packed source
-  if (silu) {
-    const int wg = tile / tiles, t = tile % tiles;
-    const int lr = (t >> 1) * rows + b;
-    if (lr < grp_rows) {
-      const int n = wg * grp_rows + lr;                                 // gate / up row index
-      nd = (n >> 4) * 32 + (t & 1) * 16 + (n & 15);
-    }
-  } else {
-    nd = tile * rows + b;
-  }
+  const int nd = tile * rows + b;                                       // row of the 16-row packed source
   uint4 v = make_uint4(0, 0, 0, 0);
-  if (nd >= 0 && nd < N) v = *reinterpret_cast<const uint4*>(src + ((int64_t)(nd >> 4) * KT + j) * 512 + (kg * 16 + (nd & 15)) * 8);
+  if (nd < N) v = *reinterpret_cast<const uint4*>(src + ((int64_t)(nd >> 4) * KT + j) * 512 + (kg * 16 + (nd & 15)) * 8);
   *reinterpret_cast<uint4*>(dst + idx * 8) = v;
 }
 
@@ -127,7 +111,7 @@ int launch_repack_rows(const bf16_t* packed16, bf16_t* dst, int N, int K, int ep
   FMI_REQUIRE(plan.ok, "repack_rows: no row-balanced plan for N=%d K=%d", N, K);
   const int64_t total = plan.elems / 8;
   hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed16, dst, N, K,
-                     epi == EPI_SILU ? 1 : 0, plan.rows, plan.tiles, plan.grp_rows, total);
+                     plan.rows, total);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -408,7 +392,7 @@ template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool PAIRX, bool NT
 __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a) {
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
   static_assert(!Q8 || PAIRX, "the int8 stream is the M <= 8 decode path");
-  static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || !Q8), "row-balanced tiles: bf16 only");
+  static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || (!Q8 && EPI != EPI_SILU)), "row-balanced tiles: bf16, no SwiGLU");
   constexpr int TSTRIDE = ROWS * 4;   // u32x4 per (tile, k-tile): ROWS rows x 4 lane groups
   __shared__ float red[WAVES][TILES][256];
   __shared__ float s_rstd[16];
@@ -604,11 +588,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
       } else {  // SwiGLU: even tiles = gate rows, odd tiles = up rows (llama.py:987)
 #pragma unroll
         for (int t = 0; t < TILES; t += 2) {
-          // row-balanced copy: a work-group owns a.grp_rows consecutive gate rows (and their up rows) in TILES / 2
-          // tile pairs of ROWS rows, the last pair padded (launch_repack_rows)
-          const int lr = (t >> 1) * ROWS + r;
-          if (ROWS != 16 && lr >= a.grp_rows) continue;
-          const int n = ROWS == 16 ? ((tile0 + t) >> 1) * 16 + r : (int)blockIdx.x * a.grp_rows + lr;
+          const int n = ((tile0 + t) >> 1) * 16 + r;
           float gate = rbf(silu_f(v[t]));
           float up = v[t + 1 < TILES ? t + 1 : t];
           a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
@@ -644,13 +624,13 @@ static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
 }
 
 // Row-balanced variants (M <= 8, bf16): the instantiations that exist, i.e. the S2-Pro decode shapes whose 16-row
-// tilings leave CUs idle -- wo / w2 (N = 2560: 10 rows x 256 work-groups), wqkv (N = 6144: 2 x 12 rows x 256) and
-// w1|w3 (N = 2 x 9728: 19 gate + 19 up rows x 512 work-groups, as 2 x (10 + 10) with one zero row per pair).
+// tilings leave CUs idle -- wo / w2 (N = 2560: 10 rows x 256 work-groups) and wqkv (N = 6144: 2 x 12 rows x 256).
+// Measured on MI355X (tools/gemv_rows_bench.hip, profiles/r03_gemv_rows_bench.txt), bit-identical outputs:
+// wo 6.5-6.6 -> 6.3 us, w2 12.4-14.7 -> 12.2, wqkv 10.3-10.5 -> 10.05; decode frame 4.73 -> 4.60 ms.
 template <int WAVES, int UNR, int TILES, int ROWS, int EPI_, bool NORM_>
 static int launch_skinny_rows(const LinearArgs& a, const RowPlan& p, hipStream_t s) {
   LinearArgs b = a;
   b.wp = a.wr;
-  b.grp_rows = p.grp_rows;
   hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true, true, false, ROWS>), dim3(p.wgs),
                      dim3(WAVES * 64), 0, s, b);
   FMI_CHECK_HIP(hipGetLastError());
@@ -660,7 +640,6 @@ static int launch_skinny_rows(const LinearArgs& a, const RowPlan& p, hipStream_t
 bool skinny_rows_supported(int N, int K, int epi, bool norm) {
   const RowPlan p = skinny_row_plan(N, K, epi);
   if (!p.ok) return false;
-  if (epi == EPI_SILU) return norm && p.rows == 10 && p.tiles == 4;
   if (epi == EPI_RESIDUAL) return !norm && p.rows == 10 && p.tiles == 1;
   return norm && p.rows == 12 && p.tiles == 2;
 }
@@ -683,7 +662,6 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   const int ntile = a.N / 16;
   if (a.wr && a.M <= 8 && !a.wq && !a.scale && skinny_rows_supported(a.N, a.K, a.epi, a.norm_w != nullptr)) {
     const RowPlan p = skinny_row_plan(a.N, a.K, a.epi);
-    if (a.epi == EPI_SILU) return launch_skinny_rows<8, 1, 4, 10, EPI_SILU, true>(a, p, s);
     if (a.epi == EPI_RESIDUAL) return launch_skinny_rows<8, 2, 1, 10, EPI_RESIDUAL, false>(a, p, s);
     return launch_skinny_rows<8, 1, 2, 12, EPI_STORE, true>(a, p, s);
   }
@@ -823,6 +801,8 @@ __device__ inline u32x4 lds_read_b128(unsigned addr) {
   return v;
 }
 
+constexpr char FMI_GEMM_DEFAULT = 'w';   // prefill GEMM variant when FMI_GEMM is unset: wave-specialised (8 x 200 rows: 30.3 -> 25.4 ms, 8 x 2048: 225.9 -> 215.1 ms on MI355X; bit-identical)
+
 template <int EPI>
 __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][A 16 pieces | B 16 pieces] x 1 KiB
@@ -927,14 +907,166 @@ __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
   }
 }
 
-int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct) {
+// Wave-specialised variant of the LDS-staged prefill GEMM (round 3).  Same tile, same LDS images, same MFMA order per
+// output element (identical results) -- but the work-group has EIGHT waves: waves 0-3 only read operands from LDS and
+// issue MFMAs, waves 4-7 only issue the LDS-DMA of the next k-step.  Why: a 128 x 128 x 64 step moves 32 KiB through
+// the CU's texture-addresser path (64 B/clk: 512 cycles) for 128 MFMAs (16 cycles each on 4 SIMDs: 512 cycles) --
+// the tile sits exactly on the ridge, so the two must OVERLAP to get anywhere, and in the 4-wave kernel the wave that
+// issues a DMA piece (60-185 cycles each, MI355X_MICROARCH.md) is the wave whose MFMAs then starve.  The cyclic
+// wave -> SIMD placement puts one compute and one loader wave of a work-group on every SIMD.  Operand reads of the
+// second k-tile are issued before the first k-tile's MFMAs.
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void linear_tiled_ws_kernel(LinearArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][A 16 pieces | B 16 pieces] x 1 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int KT = a.K >> 5, KS = (KT + 1) >> 1;  // k-steps of two k-tiles (the last may hold one)
+  const int NT = a.N >> 4;
+  const int n_blk0 = blockIdx.x * 8, m_blk0 = blockIdx.y * 128;
+  const int mi = lane & 15, g = lane >> 4;
+  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
+
+  auto stage = [&](int ks, int buf) {
+    char* base = smem + buf * 32768;
+    for (int p = wave; p < 32; p += 4) {       // pieces 0-15: weights, 16-31: activations; piece = tile*2 + kk
+      const int kk = p & 1, j = 2 * ks + kk;
+      if (j >= KT) continue;                   // unpaired last k-tile: second half of the step is empty
+      if (p < 16) {
+        const int nt = min(n_blk0 + (p >> 1), NT - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + ((int64_t)nt * KT + j) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+      } else {
+        const int mt = (p - 16) >> 1;
+        const int m = min(m_blk0 + mt * 16 + mi, a.M - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + (int64_t)m * a.ldx + packed_k0(j, g, KT)),
+                                         (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  if (loader) {
+    stage(0, 0);
+    for (int ks = 0; ks < KS; ++ks) {
+      __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this wave's pieces of step ks have landed
+      __syncthreads();                         // ... everyone's have; the compute waves are done with buffer (ks+1)&1
+      if (ks + 1 < KS) stage(ks + 1, (ks + 1) & 1);
+    }
+    return;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u;
+
+  for (int ks = 0; ks < KS; ++ks) {            // K / 32 is even here (launch_linear_tiled): every step holds two k-tiles
+    __syncthreads();
+    const unsigned b0 = lds0 + (unsigned)((ks & 1) * 32768);
+    u32x4 wv0[4], xv[4], wv1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wv0[t] = lds_read_b128(b0 + (unsigned)(((wn * 4 + t) * 2) * 1024));
+      xv[t] = lds_read_b128(b0 + (unsigned)((16 + (wm * 4 + t) * 2) * 1024));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wv1[t] = lds_read_b128(b0 + (unsigned)(((wn * 4 + t) * 2 + 1) * 1024));
+    // (the waits name the registers they make valid: MFMA builtins are not memory operations, so nothing else keeps
+    // the compiler from scheduling a product above the wait for its operand)
+    asm volatile("s_waitcnt lgkmcnt(4)"   // the first k-tile's eight reads are back
+                 : "+v"(wv0[0]), "+v"(wv0[1]), "+v"(wv0[2]), "+v"(wv0[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
+                 :: "memory");
+    // activation-tile-major order: once the four products of activation tile tm are issued its register is free
+    // for the SECOND k-tile's fragment, which then arrives under the remaining products (128-register budget:
+    // two work-groups = four waves per SIMD)
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv0[tn]),
+                                                              *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
+      xv[tm] = lds_read_b128(b0 + (unsigned)((16 + (wm * 4 + tm) * 2 + 1) * 1024));
+      __builtin_amdgcn_sched_barrier(0);   // keep each reload right behind the products that freed its register
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(wv1[0]), "+v"(wv1[1]), "+v"(wv1[2]), "+v"(wv1[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
+                 :: "memory");
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv1[tn]),
+                                                              *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
+  }
+
+  // epilogue identical to the other variants: lane holds D[n = tile*16 + g*4 + j][m = tile*16 + mi]
+  const int n_tile0 = n_blk0 + wn * 4, m0 = m_blk0 + wm * 64;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + tm * 16 + mi;
+    if (m >= a.M) continue;
+    if (EPI == EPI_SILU) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int nt_gate = n_tile0 + tp * 2;
+        if (nt_gate >= NT) continue;
+        const int n = (nt_gate >> 1) * 16 + g * 4;
+        bf16_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gate = rbf(silu_f(lin_out(acc[tp * 2][tm][j], a.scale, nt_gate * 16 + g * 4 + j)));
+          float up = lin_out(acc[tp * 2 + 1][tm][j], a.scale, (nt_gate + 1) * 16 + g * 4 + j);
+          o[j] = f2bf(gate * up);
+        }
+        *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        if (n_tile0 + tn >= NT) continue;
+        const int n = (n_tile0 + tn) * 16 + g * 4;
+        bf16_t o[4];
+        if (EPI == EPI_RESIDUAL) {
+          uint2 rv = *reinterpret_cast<const uint2*>(a.res + (int64_t)m * a.ldr + n);
+          const bf16_t* re = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(re[j]) + lin_out(acc[tn][tm][j], a.scale, n + j));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(lin_out(acc[tn][tm][j], a.scale, n + j));
+        }
+        *reinterpret_cast<uint2*>(a.out + (int64_t)m * a.ldo + n) = *reinterpret_cast<uint2*>(o);
+      }
+    }
+  }
+}
+
+int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, int variant) {
   FMI_REQUIRE(a.norm_w == nullptr, "linear_tiled: fused norm not supported (use rmsnorm_rows)");
   FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0 && a.ldo % 4 == 0, "linear_tiled: bad shape");
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_tiled: SwiGLU needs N %% 32");
   dim3 grid(cdiv(a.N / 16, 8), cdiv(a.M, 128)), block(256);
-  static const bool env_direct = []() { const char* e = getenv("FMI_GEMM"); return e && e[0] == 'd'; }();  // A/B switch
-  if (!env_direct && !force_direct) {
-    constexpr int smem = 2 * 32768;
+  // A/B switch: FMI_GEMM = d (operands straight from L2), l (LDS-staged, 4 waves), w (LDS-staged, wave-specialised)
+  static const char env_mode = []() { const char* e = getenv("FMI_GEMM"); return e ? e[0] : '\0'; }();
+  char mode = force_direct ? 'd' : variant == 1 ? 'l' : variant == 2 ? 'w' : env_mode ? env_mode : FMI_GEMM_DEFAULT;
+  if (mode == 'w' && ((a.K >> 5) & 1)) mode = 'l';   // the wave-specialised loop takes k-tiles in pairs
+  constexpr int smem = 2 * 32768;
+  if (mode == 'w') {
+    static const hipError_t at0 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t at1 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t at2 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    FMI_CHECK_HIP(at0); FMI_CHECK_HIP(at1); FMI_CHECK_HIP(at2);
+    if (a.epi == EPI_STORE) hipLaunchKernelGGL(linear_tiled_ws_kernel<EPI_STORE>, grid, dim3(512), smem, s, a);
+    else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL(linear_tiled_ws_kernel<EPI_RESIDUAL>, grid, dim3(512), smem, s, a);
+    else hipLaunchKernelGGL(linear_tiled_ws_kernel<EPI_SILU>, grid, dim3(512), smem, s, a);
+    FMI_CHECK_HIP(hipGetLastError());
+    return FMI_OK;
+  }
+  if (mode != 'd') {
     static const hipError_t at0 = hipFuncSetAttribute((const void*)linear_tiled_lds_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     static const hipError_t at1 = hipFuncSetAttribute((const void*)linear_tiled_lds_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     static const hipError_t at2 = hipFuncSetAttribute((const void*)linear_tiled_lds_kernel<EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -2255,7 +2387,11 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     }
   wc[lane] = w;
   __syncthreads();
-  if (wave != 0 || a.dbg_stop == 5) return;
+  // the rows gathered for the next fast step (embedding, tabulated layer-0 q|k|v) are fetched by ALL waves once wave 0
+  // knows the code: 17 dependent load -> store trips of one wave (5 + 12 KB at the S2 shape) were ~10 us of this kernel
+  const bool gather_all = a.xf != nullptr && a.dbg_stop == 0 && a.mode != 2;
+  int tok = 0;
+  if (wave == 0 && a.dbg_stop != 5) {
   auto merge_desc = [&](uint32_t x, uint32_t y_rev) -> uint32_t {   // x sorted desc, y_rev = other list reversed
     uint32_t m = max(x, y_rev);
 #pragma unroll
@@ -2294,7 +2430,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   }
 
   if (a.dbg_stop == 6) return;
-  int tok = small_draw(v, cum, vid, lane, k, temperature, top_p, seed, 0u /* stream: an utterance's draws depend on its seed only, not on the slot it occupies */, (uint32_t)frame, (uint32_t)draw0);
+  tok = small_draw(v, cum, vid, lane, k, temperature, top_p, seed, 0u /* stream: an utterance's draws depend on its seed only, not on the slot it occupies */, (uint32_t)frame, (uint32_t)draw0);
   if (a.dbg_stop == 7) return;
   if (a.mode == 1) {
     if (lane == 0) a.st.cur[(int64_t)slot * a.st.ncb1 + 1 + a.cb] = tok;
@@ -2323,16 +2459,43 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     }
     tok = cb0;
   }
+  if (lane == 0) sh.sel[0] = tok;
+  } else if (!gather_all) {
+    return;
+  }
   if (a.xf) {  // fast_embeddings[code] -> next fast step's input (inference.py:157,172)
-    const bf16_t* src = a.fast_emb + (int64_t)tok * a.fdim;
-    for (int c = lane * 8; c < a.fdim; c += 64 * 8)
-      *reinterpret_cast<uint4*>(a.xf + (int64_t)b * a.fdim + c) = *reinterpret_cast<const uint4*>(src + c);
-    if (a.qkv0_tab) {  // ... and the first fast layer's q|k|v of that code (precomputed with the very same GEMV)
-      const bf16_t* q = a.qkv0_tab + (int64_t)tok * a.qkv0_dim;
-      for (int c = lane * 8; c < a.qkv0_dim; c += 64 * 8)
-        *reinterpret_cast<uint4*>(a.qkv0_out + (int64_t)b * a.qkv0_dim + c) = *reinterpret_cast<const uint4*>(q + c);
+    if (gather_all) {
+      __syncthreads();
+      tok = sh.sel[0];
+    } else if (wave != 0) {
+      return;
+    }
+    // ... and the first fast layer's q|k|v of that code (precomputed with the very same GEMV); every load of a
+    // thread is requested before its first store
+    const int n1 = a.fdim >> 3, n2 = a.qkv0_tab ? (a.qkv0_dim >> 3) : 0;
+    const uint4* src1 = reinterpret_cast<const uint4*>(a.fast_emb + (int64_t)tok * a.fdim);
+    const uint4* src2 = a.qkv0_tab ? reinterpret_cast<const uint4*>(a.qkv0_tab + (int64_t)tok * a.qkv0_dim) : nullptr;
+    uint4* dst1 = reinterpret_cast<uint4*>(a.xf + (int64_t)b * a.fdim);
+    uint4* dst2 = a.qkv0_tab ? reinterpret_cast<uint4*>(a.qkv0_out + (int64_t)b * a.qkv0_dim) : nullptr;
+    const int nthr = gather_all ? 256 : 64, t0 = gather_all ? tid : lane;
+    constexpr int GB = 6;
+    for (int base = 0; base < n1 + n2; base += GB * nthr) {
+      uint4 gv[GB];
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        const int i = base + t0 + j * nthr;
+        if (i < n1) gv[j] = src1[i];
+        else if (i < n1 + n2) gv[j] = src2[i - n1];
+      }
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        const int i = base + t0 + j * nthr;
+        if (i < n1) dst1[i] = gv[j];
+        else if (i < n1 + n2) dst2[i - n1] = gv[j];
+      }
     }
   }
+  if (wave != 0) return;
   if (a.mode == 1 && a.cb == a.st.ncb1 - 2 && lane == 0) {  // frame bookkeeping, as in sample_kernel
     const int ncb1 = a.st.ncb1;
     int32_t* cur = a.st.cur + (int64_t)slot * ncb1;

@@ -99,24 +99,31 @@ class DacConfig:
         return c
 
 
-def fold_weight_norm(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+def fold_weight_norm(state: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
     """codec.pth keys -> plain weights: w = g * v / ||v|| over all dims but 0, for both weight-norm
     spellings (parametrizations.weight.original0/1, modded_dac.py:554-556; weight_g/weight_v of the
-    third-party quantizer projections).  SURVEY.md A.6."""
+    third-party quantizer projections).  SURVEY.md A.6.
+
+    dtype = torch.bfloat16: the parameters of `codec.to(dtype=torch.bfloat16)` (how the text2semantic CLI holds the
+    codec, text2semantic/inference.py:416): g, v and every other floating tensor are rounded to bf16 and the weight-norm
+    product is evaluated in bf16 by the same torch function the parametrization calls."""
+    def c(t):
+        return t.to(dtype) if t.is_floating_point() else t
+
     out = {}
     for k, v in state.items():
         if k.endswith("parametrizations.weight.original1"):
             base = k[: -len("parametrizations.weight.original1")]
-            out[base + "weight"] = torch._weight_norm(v.float(), state[base + "parametrizations.weight.original0"].float(), 0)
+            out[base + "weight"] = torch._weight_norm(c(v.float()), c(state[base + "parametrizations.weight.original0"].float()), 0)
         elif k.endswith("weight_v"):
             base = k[: -len("weight_v")]
-            out[base + "weight"] = torch._weight_norm(v.float(), state[base + "weight_g"].float(), 0)
+            out[base + "weight"] = torch._weight_norm(c(v.float()), c(state[base + "weight_g"].float()), 0)
         elif k.endswith("parametrizations.weight.original0") or k.endswith("weight_g"):
             continue
         elif "causal_mask" in k or "freqs_cis" in k:
             continue
         else:
-            out[k] = v
+            out[k] = c(v)
     return out
 
 
@@ -218,6 +225,8 @@ class MiDAC:
         `from_checkpoint` (released weights were never run through this path); off for in-memory states."""
         self.check_overflow = bool(check_overflow)
         self.overflow_fallbacks = 0
+        self.module_dtype = torch.float32      # torch.bfloat16 after .to(dtype=torch.bfloat16): the text2semantic CLI's mode
+        self._raw_state = None                 # the state dict last loaded (kept by reference for .to(dtype=...))
         self.lib = _lib.load()
         self.config = config if isinstance(config, DacConfig) else (DacConfig.from_any(config) if config else DacConfig())
         self.device = torch.device(device)
@@ -246,7 +255,29 @@ class MiDAC:
             self._h = None
 
     def parameters(self) -> Iterable[torch.Tensor]:
-        yield self._dtype_probe
+        yield self._dtype_probe             # carries the module dtype, like next(codec.parameters()).dtype upstream
+
+    def to(self, *args, **kwargs):
+        """nn.Module.to for the one thing callers use it for (text2semantic/inference.py:416
+        `codec.to(device=device, dtype=precision)`): dtype=torch.bfloat16 switches the whole codec to bf16-module
+        numerics -- parameters rounded to bf16 (weight-norm products evaluated in bf16), every conv / linear with bf16
+        operands and a bf16 result, bf16 audio in and out; torch.float32 switches back.  Elementwise ops between the
+        contractions keep fp32 intermediates (torch rounds each to bf16): the same network within bf16 rounding noise,
+        calibrated against the oracle in that mode in tests/test_dac_gpu.py.  fp16 is refused."""
+        dtype = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+        if dtype is None or dtype == self.module_dtype:
+            return self
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.FishmiError(f"MiDAC.to(dtype={dtype}): only float32 and bfloat16 are implemented")
+        if self._raw_state is None:
+            raise _lib.FishmiError("MiDAC.to(dtype=...): load a state dict first (the parameters are re-rounded from it)")
+        self.load_folded_state(fold_weight_norm(self._raw_state, dtype))
+        self.module_dtype = dtype
+        self._dtype_probe = torch.empty(0, dtype=dtype, device=self.device)
+        return self
 
     def eval(self):
         return self
@@ -263,7 +294,8 @@ class MiDAC:
             state = state["state_dict"]
         if any("generator" in k for k in state):
             state = {k.replace("generator.", ""): v for k, v in state.items() if "generator." in k}
-        return self.load_folded_state(fold_weight_norm(state), strict=strict)
+        self._raw_state = state
+        return self.load_folded_state(fold_weight_norm(state, self.module_dtype), strict=strict)
 
     def load_folded_state(self, folded: Dict[str, torch.Tensor], strict: bool = True):
         """Plain (already weight-norm-folded) tensors by name; see expected_state_shapes()."""
@@ -303,7 +335,9 @@ class MiDAC:
         norms and residual adds stay fp32 (torch's type promotion gives fp32 there too, parameters being fp32).
         Outside autocast the configured precision applies (default: the fp32-class fp16-split arithmetic)."""
         planes = self._planes
-        if torch.is_autocast_enabled("cuda"):
+        if self.module_dtype == torch.bfloat16:
+            planes = 1
+        elif torch.is_autocast_enabled("cuda"):
             if torch.get_autocast_dtype("cuda") != torch.bfloat16:
                 raise _lib.FishmiError("MiDAC supports autocast(dtype=torch.bfloat16) only (the engine's --half fp16 mode "
                                        "is not implemented)")
@@ -343,8 +377,9 @@ class MiDAC:
         if any("generator" in k for k in state):
             state = {k.replace("generator.", ""): v for k, v in state.items() if "generator." in k}
         folded = fold_weight_norm(state)
-        return cls(DacConfig.from_state_dict(folded, **config_overrides), device=device,
-                   check_overflow=True).load_folded_state(folded)
+        m = cls(DacConfig.from_state_dict(folded, **config_overrides), device=device, check_overflow=True)
+        m._raw_state = state
+        return m.load_folded_state(folded)
 
     # ---- DAC.encode (modded_dac.py:874-923)
     @torch.no_grad()
@@ -354,7 +389,10 @@ class MiDAC:
         length = audio_data.shape[-1]
         fl = self.frame_length
         right = math.ceil(length / fl) * fl - length
-        audio = torch.nn.functional.pad(audio_data.to(device=self.device, dtype=torch.float32), (0, right)).contiguous()
+        audio_data = audio_data.to(device=self.device)
+        if self.module_dtype == torch.bfloat16:   # the CLI hands the bf16 module bf16 samples (inference.py:431)
+            audio_data = audio_data.to(torch.bfloat16)
+        audio = torch.nn.functional.pad(audio_data.to(torch.float32), (0, right)).contiguous()
         if audio_lengths is None:
             audio_lengths = torch.tensor([length + right], device=self.device, dtype=torch.long)
         B, _, N = audio.shape
@@ -383,7 +421,7 @@ class MiDAC:
             except Exception:
                 pass
         self._keep = work
-        return out
+        return out.to(self.module_dtype) if self.module_dtype != torch.float32 else out
 
     # ---- incremental decode for streaming: audio of frames [t0, T) given all codes so far.  Bit-identical to
     # from_indices(final codes)[..., t0*frame_length : T*frame_length] because every codec layer is causal

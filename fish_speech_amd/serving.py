@@ -1,0 +1,157 @@
+"""One engine loop that streams AND refills slots (BASELINE.json configs 4 + 5 together).
+
+The reference serves one request at a time (fish_speech/inference_engine/__init__.py:73-140 pulls one
+`GenerateRequest` through its single-worker llama queue, text2semantic/inference.py:748-799) and emits audio per text
+chunk.  `scheduler.generate_queue` adds continuous batching (finished slots are refilled), `stream.generate_stream`
+adds frame-granular audio -- but only for utterances started together.  `serve_stream` combines them: up to
+`max_batch` utterances are in flight, every one on its OWN chunk schedule counted from its own first frame, a finished
+utterance's slot is refilled at the next poll, and every utterance's audio equals what the offline path
+(`generate` + `from_indices`) produces for it, bit for bit (tests/test_stream_gpu.py).
+
+Mechanics: all live slots advance together by `step_frames` frames per `MiDualAR.decode` call (one hipGraph replay
+per frame); after each advance the loop decodes, for every utterance whose schedule is due, the frames it has not
+voiced yet with `MiDAC.from_indices_tail(stream_id=...)` -- the codec keeps one quantizer-side state per open stream
+(csrc/dac.hip: select_stream_state).  Like `generate_long` (inference.py:708) the last generated frame of an
+utterance is never voiced."""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Iterable, Iterator, List, Optional
+
+import torch
+
+from .stream import chunk_schedule
+
+
+@dataclass
+class StreamRequest:
+    prompt: torch.Tensor                     # (1+ncb, T) like the reference's `generate`
+    max_new_tokens: int = 0                  # 0 = up to max_seq_len
+    seed: Optional[int] = None
+    rid: int = -1                            # caller's id, echoed in the events
+    arrival: float = 0.0                     # seconds after the loop starts at which the request exists
+
+
+@dataclass
+class StreamEvent:
+    rid: int
+    kind: str                                # "segment" | "final"
+    t0: int                                  # first frame of the segment
+    t1: int                                  # one past its last frame
+    audio: Optional[torch.Tensor]            # (1, 1, (t1 - t0) * frame_length) fp32 on the device ("segment")
+    codes: Optional[torch.Tensor]            # (num_codebooks, t1 - t0) int64 on the device ("segment")
+    t_emit: float                            # seconds since the loop started
+    first_audio_latency: Optional[float] = None   # on an utterance's first segment: t_emit - max(arrival, 0)
+
+
+@dataclass
+class _Live:
+    req: StreamRequest
+    slot: int
+    limit: int                               # frames this utterance may generate
+    marks: List[int]                         # generated-frame counts at which audio is due
+    generated: int = 1                       # frames generated so far (the prefill makes frame 0)
+    emitted: int = 0                         # frames voiced so far
+    stream_id: int = 0
+    length: Optional[int] = None             # final frame count once the utterance ended
+    first_done: bool = False
+    events: list = field(default_factory=list)
+
+
+@torch.no_grad()
+def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: Optional[int] = None,
+                 step_frames: int = 8, first_chunk_frames: int = 8, chunk_frames: int = 32, chunk_growth: float = 2.0,
+                 max_chunk_frames: int = 256, temperature: float = 1.0, top_p: float = 0.9, top_k: int = 30,
+                 use_ras: bool = True, clock: Callable[[], float] = time.perf_counter,
+                 wait: Callable[[float], None] = time.sleep) -> Iterator[StreamEvent]:
+    """Serve `requests` (any iterable, consumed lazily in order) through `max_batch` slots; yields StreamEvents as
+    audio becomes available.  A request is admitted once `clock() - start >= request.arrival` and a slot is free."""
+    cfg = model.config
+    if not model._cache_setup_done:
+        model.setup_caches(max_batch_size=max_batch or 8, max_seq_len=cfg.max_seq_len)
+    B = min(max_batch or model.max_batch_size, model.max_batch_size)
+    if step_frames < 1:
+        raise ValueError("step_frames must be >= 1")
+    it = iter(requests)
+    pending: Optional[StreamRequest] = None
+    exhausted = False
+    free = list(range(B - 1, -1, -1))
+    live: dict = {}
+    start = clock()
+    fl = codec.frame_length
+
+    def next_request():
+        nonlocal pending, exhausted
+        if pending is None and not exhausted:
+            try:
+                pending = next(it)
+            except StopIteration:
+                exhausted = True
+        return pending
+
+    while True:
+        # ---- admission: every arrived request that finds a free slot is prefilled in ONE call
+        new: List[_Live] = []
+        while free and next_request() is not None and clock() - start >= pending.arrival:
+            r, pending = pending, None
+            T = r.prompt.size(1)
+            if T >= cfg.max_seq_len:  # inference.py:263-266
+                raise ValueError(f"Input sequence length {T} exceeds max_seq_len {cfg.max_seq_len}")
+            limit = min(r.max_new_tokens if r.max_new_tokens else cfg.max_seq_len - T, cfg.max_seq_len - T)
+            marks = chunk_schedule(limit, first_chunk_frames + 1, chunk_frames, chunk_growth, max_chunk_frames)
+            new.append(_Live(r, free.pop(), limit, marks, stream_id=codec.new_stream_id()))
+        if new:
+            samp = [model._sampling(temperature, top_p, top_k, u.req.seed if u.req.seed is not None else model.next_seed(),
+                                    use_ras) for u in new]
+            model.prefill([u.slot for u in new], [u.req.prompt for u in new], [u.limit for u in new], samp)
+            live.update({u.slot: u for u in new})
+        if not live:
+            if next_request() is None:
+                return
+            wait(max(0.0, pending.arrival - (clock() - start)))      # idle until the next arrival
+            continue
+        # ---- advance every live utterance
+        slots = sorted(live)
+        need = min(step_frames, max(u.limit - u.generated for u in live.values()))
+        if need > 0:
+            model.decode(slots, need)
+        done = model.poll_done(slots)
+        for s, d in zip(slots, done):
+            u = live[s]
+            u.generated = min(u.limit, u.generated + need)
+            if u.length is None and (d or u.generated >= u.limit):
+                u.length = model.read(s)[0].shape[0] if d else u.limit
+        # ---- voice what is due: the newest frame of a live utterance is held back, the last one never voiced
+        for s in slots:
+            u = live[s]
+            ended = u.length is not None
+            voiced = (u.length if ended else u.generated) - 1
+            due = ended or any(u.emitted < m - 1 <= voiced for m in u.marks)
+            if due and voiced > u.emitted:
+                frames = model.frames_device(model.max_batch_size, voiced)[s]          # (voiced, 1+ncb) int32
+                codes = frames[:, 1:].t().to(torch.int64).contiguous()                  # (ncb, voiced)
+                audio = codec.from_indices_tail(codes[None], u.emitted, stream_id=u.stream_id)
+                now = clock() - start
+                ev = StreamEvent(u.req.rid, "segment", u.emitted, voiced, audio, codes[:, u.emitted:voiced], now)
+                if not u.first_done:
+                    ev.first_audio_latency = now - max(u.req.arrival, 0.0)
+                    u.first_done = True
+                u.emitted = voiced
+                yield ev
+            if ended:
+                yield StreamEvent(u.req.rid, "final", 0, u.emitted, None, None, clock() - start)
+                model.release(s)
+                del live[s]
+                free.append(s)
+
+
+def collect(events: Iterable[StreamEvent], frame_length: int):
+    """Concatenate every utterance's segments: {rid: (audio (n * frame_length,) fp32 CPU, codes (ncb, n) CPU)}."""
+    parts: dict = {}
+    for ev in events:
+        if ev.kind == "segment":
+            a, c = parts.setdefault(ev.rid, ([], []))
+            a.append(ev.audio[0, 0].float().cpu())
+            c.append(ev.codes.cpu())
+    return {rid: (torch.cat(a) if a else torch.zeros(0), torch.cat(c, dim=1) if c else None) for rid, (a, c) in parts.items()}

@@ -246,7 +246,9 @@ def _cli():
             nonlocal codec
             if codec is None:
                 from .dac import MiDAC
-                codec = MiDAC.from_checkpoint(checkpoint_path / "codec.pth", device=device)
+                # load_codec_model (inference.py:395-417): codec.to(device=device, dtype=precision), precision = bf16 --
+                # the CLI runs the codec as a bf16 MODULE (parameters, activations and audio in bf16)
+                codec = MiDAC.from_checkpoint(checkpoint_path / "codec.pth", device=device).to(dtype=torch.bfloat16)
             return codec
 
         prompt_list = None

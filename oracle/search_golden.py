@@ -46,6 +46,33 @@ def greedy_min_margin(cfg, trace):
     return float(O.greedy_frame_margins(cfg, slow, fast).min())
 
 
+def sampled_frame_is_robust(cfg, f, frame_tokens, slow_logits, fast_logits, window, temp, tp, top_k, useed, ulps, trials,
+                            gen, bias):
+    """One frame of a sampled run: re-derive its decisions from the traced logits and the generator's uniforms and test
+    each under logit noise.  frame_tokens: (1+ncb,) the run's tokens of this frame; window: RAS window BEFORE the
+    frame (None for the prefill frame).  Returns (robust, slow token is not the top-1 candidate, RAS fired)."""
+    dt = slow_logits.dtype
+    u = lambda d, n: (torch.from_numpy(O.fmi_uniform_u8(useed, 0, f, d, n).astype("float32")) / 256.0).to(dt)
+    biased = slow_logits + bias
+    w0 = window[0].clone() if window is not None else None
+    u_n, u_h = u(0, cfg.vocab_size), u(1, cfg.vocab_size)
+    dec = lambda lg: O.slow_decision(cfg, lg, temp, tp, top_k, u_n, u_h, w0)
+    tok = dec(biased)
+    assert tok == int(frame_tokens[0]), (f, tok, int(frame_tokens[0]))
+    non_top1 = int(tok != int(biased.float().argmax()))
+    ras = int(w0 is not None and bool((w0 == int(O.draw(O.logits_to_probs(biased, temp, tp, top_k), u_n))).any()))
+    if not O.decision_noise_margin(dec, biased, ulps, trials, gen):
+        return False, non_top1, ras
+    for cb in range(1, cfg.num_codebooks):
+        lg = fast_logits[cb - 1]
+        u_c = u(1 + cb, cfg.codebook_size)
+        decf = lambda l: int(O.draw(O.logits_to_probs(l, temp, tp, top_k), u_c))
+        assert decf(lg) == int(frame_tokens[1 + cb]), (f, cb)
+        if not O.decision_noise_margin(decf, lg, ulps, trials, gen):
+            return False, non_top1, ras
+    return True, non_top1, ras
+
+
 def sampled_run_is_robust(cfg, y, trace, T, temperature, top_p, top_k, useed, ulps=NOISE_ULPS, trials=24):
     """Re-derive every decision of a sampled run from its traced logits and the generator's uniforms and test it
     under logit noise.  Returns (robust, n_non_top1, n_ras)."""
@@ -59,25 +86,12 @@ def sampled_run_is_robust(cfg, y, trace, T, temperature, top_p, top_k, useed, ul
     non_top1 = ras = 0
     n_frames = y.shape[1] - T
     for f in range(n_frames):
-        u = lambda d, n: (torch.from_numpy(O.fmi_uniform_u8(useed, 0, f, d, n).astype("float32")) / 256.0).to(dt)
-        biased = trace["slow_logits"][f] + bias
-        w0 = window[0].clone() if f > 0 else None
-        u_n, u_h = u(0, cfg.vocab_size), u(1, cfg.vocab_size)
-        dec = lambda lg: O.slow_decision(cfg, lg, temp, tp, top_k, u_n, u_h, w0)
-        tok = dec(biased)
-        assert tok == int(y[0, T + f]), (f, tok, int(y[0, T + f]))
-        if not O.decision_noise_margin(dec, biased, ulps, trials, gen):
+        ok, nt, rs = sampled_frame_is_robust(cfg, f, y[:, T + f], trace["slow_logits"][f], trace["fast_logits"][f],
+                                             window if f > 0 else None, temp, tp, top_k, useed, ulps, trials, gen, bias)
+        non_top1 += nt
+        ras += rs
+        if not ok:
             return False, non_top1, ras
-        non_top1 += int(tok != int(biased.float().argmax()))
-        if w0 is not None and bool((w0 == int(O.draw(O.logits_to_probs(biased, temp, tp, top_k), u_n))).any()):
-            ras += 1
-        for cb in range(1, cfg.num_codebooks):
-            lg = trace["fast_logits"][f][cb - 1]
-            u_c = u(1 + cb, cfg.codebook_size)
-            decf = lambda l: int(O.draw(O.logits_to_probs(l, temp, tp, top_k), u_c))
-            assert decf(lg) == int(y[1 + cb, T + f]), (f, cb)
-            if not O.decision_noise_margin(decf, lg, ulps, trials, gen):
-                return False, non_top1, ras
         if f > 0:
             window = window.roll(-1, dims=1)
             window[:, -1] = y[:, T + f].int()

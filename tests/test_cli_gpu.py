@@ -150,10 +150,14 @@ def test_text2semantic_cli_with_prompt_audio_and_wav_output(tmp_path, monkeypatc
     assert codes.shape[0] == 10 and 1 <= codes.shape[1] <= 8 and codes.min() >= 0 and codes.max() < 4096
     sr, y = wavfile.read(str(tmp_path / "tts.wav"))
     assert sr == 44100 and y.shape[0] == codes.shape[1] * ccfg.frame_length
-    codec = MiDAC.from_checkpoint(tmp_path / "codec.pth", device=DEV)
+    # the CLI holds the codec like load_codec_model does (inference.py:416): .to(dtype=bfloat16)
+    codec = MiDAC.from_checkpoint(tmp_path / "codec.pth", device=DEV).to(dtype=torch.bfloat16)
+    assert next(codec.parameters()).dtype == torch.bfloat16
     wav = _load_wav(ref, codec.sample_rate).to(DEV)
     idx, lens = codec.encode(wav, torch.tensor([wav.shape[-1]], device=DEV))
     np.save(tmp_path / "ref.npy", idx[0, :, : int(lens[0])].cpu().numpy())
+    want_wav = codec.from_indices(torch.from_numpy(codes)[None].to(DEV))[0, 0].float().cpu().numpy()
+    assert np.array_equal(y, want_wav)                                       # the wav is the bf16 module's output
     outdir2 = tmp_path / "out2"
     r = CliRunner().invoke(_cli(), args[:-1] + [str(outdir2), "--prompt-tokens", str(tmp_path / "ref.npy")])
     assert r.exit_code == 0, r.output + repr(r.exception)

@@ -39,6 +39,33 @@ def test_oracle_decode_matches_reference_waveform(case):
     assert got.shape == (2, 1, 5 * cfg.frame_length) and float(got.abs().max()) < 1.0
 
 
+@pytest.mark.skipif(not __import__("oracle.refload", fromlist=["x"]).reference_available(),
+                    reason="reference checkout not present on this box")
+def test_oracle_in_bf16_equals_the_reference_bf16_module():
+    """The text2semantic CLI holds the codec as `codec.to(dtype=torch.bfloat16)` (inference.py:416).  The oracle
+    built from the bf16-rounded state reproduces the UNMODIFIED reference module in that mode bit for bit -- decode
+    and encode -- which is what pins the calibration target of tests/test_dac_gpu.py's bf16-module test."""
+    from oracle.gen_golden_dac import build_reference_dac
+
+    cfg = D.small_config()
+    state = D.make_synthetic_state(cfg, seed=11)
+    ref = build_reference_dac(cfg, state).to(dtype=torch.bfloat16)
+    orc = D.DacOracle(cfg, {k: (v.bfloat16() if v.is_floating_point() else v) for k, v in state.items()})
+    codes = D.make_codes(cfg, 2, 5, seed=4)
+    with torch.no_grad():
+        want = ref.from_indices(codes.clone())
+    got = orc.from_indices(codes.clone())
+    assert want.dtype == got.dtype == torch.bfloat16 and torch.equal(got, want)
+    n = 3 * cfg.frame_length - 700
+    audio = 0.2 * torch.randn(1, 1, n, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        c_ref, _ = ref.encode(audio.bfloat16(), torch.tensor([n]))
+    c_orc, _ = orc.encode(audio.bfloat16(), torch.tensor([n]))
+    assert torch.equal(c_orc, c_ref)
+    c32, _ = D.DacOracle(cfg, state).encode(audio, torch.tensor([n]))
+    print("reference bf16 encode agrees with its own fp32 codes in", float((c_ref == c32).float().mean()), "of the indices")
+
+
 def test_decoder_is_causal_prefix_consistent(case):
     """All convolutions are causal and attention is windowed-causal: decoding a prefix of the codes
     gives the prefix of the waveform (the property streaming decode relies on)."""

@@ -308,6 +308,65 @@ def test_engine_autocast_bf16_mode_vs_oracle_in_the_same_mode(full):
             codec.from_indices(codes.clone().to(DEV))
 
 
+def test_bf16_module_mode_of_the_text2semantic_cli_vs_oracle_in_the_same_mode(full):
+    """How the text2semantic CLI holds the codec (text2semantic/inference.py:416: codec.to(device, dtype=bfloat16)):
+    parameters rounded to bf16 (weight-norm products evaluated in bf16), bf16 contractions, bf16 audio.  The oracle
+    built from the bf16 state IS the reference's bf16 module bit for bit on a CPU (tests/test_dac_cpu.py), so the
+    tolerance is calibrated against it like the autocast mode's: the HIP waveform must be as close to the exact fp32
+    waveform as the reference arithmetic in that mode is (<= 1.5x its RMS distance) and within 2x that distance of the
+    bf16 oracle; .to(float32) restores the fp32-class results.  fp16 is refused."""
+    from fish_speech_amd import FishmiError
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg, state, _ = full
+    codec = MiDAC.from_state_dict(DacConfig.from_any(cfg), state, device=DEV)
+    codes = D.make_codes(cfg, 2, 4, seed=14)
+    want32 = D.DacOracle(cfg, state).from_indices(codes.clone())
+    st16 = {k: (v.bfloat16() if v.is_floating_point() else v) for k, v in state.items()}
+    want16 = D.DacOracle(cfg, st16).from_indices(codes.clone())
+    assert want16.dtype == torch.bfloat16
+    assert codec.to(dtype=torch.bfloat16) is codec and next(codec.parameters()).dtype == torch.bfloat16
+    got = codec.from_indices(codes.clone().to(DEV))
+    assert got.dtype == torch.bfloat16
+    sig = float(want32.pow(2).mean().sqrt())
+    noise, e_hip, e_x = rms(want16, want32), rms(got, want32), rms(got, want16)
+    print(f"bf16 module: signal rms {sig:.4f}; vs exact fp32: oracle {noise:.2e}, HIP {e_hip:.2e}; HIP vs bf16 oracle {e_x:.2e}")
+    assert noise > 1e-5 and e_hip <= 1.5 * noise + 1e-5 and e_x <= 2.0 * noise + 1e-5
+    # encode in this mode: bf16 parameters and bf16 audio, fp32 activations (DESIGN section 5.8: the reference's own bf16
+    # encode agrees with its fp32 codes in ~1 index of 6 on synthetic weights, so index parity is undefined upstream)
+    n = cfg.frame_length * 3
+    audio = 0.2 * torch.randn(1, 1, n, generator=torch.Generator().manual_seed(5))
+    c16, l16 = codec.encode(audio.to(DEV), torch.tensor([n], device=DEV))
+    assert c16.shape == (1, cfg.n_codebooks + 1, 3) and int(c16.max()) < cfg.semantic_codebook_size
+    codec.to(dtype=torch.float32)
+    plain = codec.from_indices(codes.clone().to(DEV))
+    assert plain.dtype == torch.float32 and rms(plain, want32) <= 1e-4
+    with pytest.raises(FishmiError):
+        codec.to(dtype=torch.float16)
+
+
+def test_fp16_split_saturates_and_flags_instead_of_producing_nans(small):
+    """the fp16-split arithmetic (default) is only defined for |x| < 65504.  Weights far outside that
+    range must give finite samples and raise the sticky overflow flag; with check_overflow=True the call is repeated
+    on the fp32 matrix cores and matches the oracle."""
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg, state, z, codec = small
+    assert not codec.fp16_overflowed()
+    big = {k: v.clone() for k, v in state.items()}
+    k0 = "decoder.model.0.conv.parametrizations.weight.original0"      # weight-norm gain of the decoder's first conv
+    big[k0] = big[k0] * 3.0e5
+    codes = D.make_codes(cfg, 1, 3, seed=9)
+    loud = MiDAC.from_state_dict(DacConfig.from_any(cfg), big, device=DEV)
+    loud.fp16_overflowed()                                                # weights beyond the range flag at load time
+    out = loud.from_indices(codes.clone().to(DEV))
+    assert bool(torch.isfinite(out).all()) and loud.fp16_overflowed() and not loud.fp16_overflowed()
+    safe = MiDAC(DacConfig.from_any(cfg), device=DEV, check_overflow=True).load_state_dict(big)
+    got = safe.from_indices(codes.clone().to(DEV))
+    want = D.DacOracle(cfg, big).from_indices(codes.clone())
+    assert safe.overflow_fallbacks == 1 and rms(got, want) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
 def test_concurrent_from_indices_from_request_threads(small):
     """request threads share the codec object (tools/api_server.py:115-122 -> get_audio_segment).  Four
     threads decode different codes at once, some inside autocast: every result equals the sequential one."""

@@ -105,6 +105,30 @@ def test_skinny_linear_row_result_is_independent_of_the_batch_size(lib, N, K, ep
         assert torch.equal(one[0], big[r]), r
 
 
+@pytest.mark.parametrize("N,K,epi,norm", [(2560, 4096, 1, False), (2560, 9728, 1, False), (6144, 2560, 0, True)])
+@pytest.mark.parametrize("M", [1, 5, 8])
+def test_row_balanced_decode_gemv_is_bit_identical_to_the_16_row_tiles(lib, N, K, epi, norm, M):
+    """The row-balanced decode copy (10 / 12 weight rows per tile so that 256 equal work-groups cover N = 2560 /
+    6144: dualar_kernels.h skinny_row_plan) holds the same products in the same order as the 16-row tiling: every
+    output equals the 16-row kernel's bit for bit, for any batch <= 8; shapes without a balanced variant are refused
+    by the forced path (the model then streams the 16-row tiles)."""
+    from fish_speech_amd import FishmiError
+
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16() if norm else None
+    res = torch.randn(M, N, generator=g).bfloat16() if epi == 1 else None
+    tiles16 = _linear(lib, x, w, nw, res, M, N, K, epi, 1)
+    rows = _linear(lib, x, w, nw, res, M, N, K, epi, 6)
+    assert torch.equal(rows, tiles16)
+    ok, mx, nbad = bf16_close(rows, _linear_oracle(x, w, nw, res, epi), scale=res)
+    assert ok, (mx, nbad)
+    if M == 8 and epi == 0:
+        with pytest.raises(FishmiError):   # 4096 rows = 16 per CU: the 16-row tiling is the balanced one
+            _linear(lib, x, w[:4096].contiguous(), nw, None, M, 4096, K, 0, 6)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(1600, 6144, 2560, 0), (1600, 2560, 4096, 1), (777, 19456, 2560, 2),
                                         (130, 2560, 9728, 1), (5, 192, 256, 0), (300, 320, 96, 2), (129, 4112, 2080, 0)])
 def test_lds_staged_prefill_gemm_equals_the_direct_variant(lib, M, N, K, epi):
@@ -115,9 +139,13 @@ def test_lds_staged_prefill_gemm_equals_the_direct_variant(lib, M, N, K, epi):
     x = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
     res = torch.randn(M, N, generator=g).bfloat16() if epi == 1 else None
-    staged = _linear(lib, x, w, None, res, M, N, K, epi, 2)
+    staged = _linear(lib, x, w, None, res, M, N, K, epi, 7)     # LDS-staged, 4 waves
     direct = _linear(lib, x, w, None, res, M, N, K, epi, 5)
     assert torch.equal(staged, direct), float((staged.float() - direct.float()).abs().max())
+    # wave-specialised variant (4 compute + 4 loader waves; falls back to the 4-wave kernel for an odd k-tile count)
+    ws = _linear(lib, x, w, None, res, M, N, K, epi, 8)
+    assert torch.equal(ws, direct), float((ws.float() - direct.float()).abs().max())
+    assert torch.equal(_linear(lib, x, w, None, res, M, N, K, epi, 2), direct)   # whichever is the default
     if M <= 300:
         ok, mx, nbad = bf16_close(staged, _linear_oracle(x, w, None, res, epi), scale=res)
         assert ok, (mx, nbad)

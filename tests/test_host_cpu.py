@@ -68,6 +68,8 @@ class StubDualAR:
     def frames_device(self, n_slots, n_frames):
         out = torch.zeros(n_slots, n_frames, NCB + 1, dtype=torch.int32)
         for s in range(n_slots):
+            if s not in self.slots:
+                continue
             k = min(n_frames, self.slots[s]["n"])
             out[s, :k] = self._frames(self.slots[s]["seed"], k)
         return out
@@ -165,6 +167,50 @@ def test_generate_stream_emits_exactly_the_offline_frames(first, chunk, growth):
     assert codec.calls[0][1] == 0
     for a, b in zip(codec.calls, codec.calls[1:]):
         assert b[1] == a[0]
+
+
+@pytest.mark.parametrize("step,first,chunk,growth", [(8, 8, 32, 2.0), (1, 1, 1, 1.0), (5, 3, 4, 1.5), (16, 2, 64, 1.0)])
+def test_serve_stream_refills_slots_and_every_utterance_equals_its_offline_result(step, first, chunk, growth):
+    """serving.serve_stream = continuous batching + per-utterance chunk schedules: 9 requests (natural lengths 4..40
+    frames, two cut by max_new_tokens) through 3 slots, arriving over time on a fake clock.  Every utterance's
+    concatenated segments are exactly its offline codes / audio (last frame never voiced), first-audio latency is
+    reported once per utterance, every slot is released, and each utterance decodes on its own codec stream id."""
+    from fish_speech_amd.serving import StreamRequest, collect, serve_stream
+
+    model, codec = StubDualAR(max_batch=3), StubCodec()
+    seeds = [3, 11, 5, 8, 2, 30, 7, 19, 4]
+    limits = [0, 0, 9, 0, 0, 12, 0, 0, 0]
+    now = [0.0]
+    reqs = [StreamRequest(prompt=torch.zeros(NCB + 1, 5 + i, dtype=torch.int64), max_new_tokens=limits[i], seed=s, rid=100 + i,
+                          arrival=0.06 * i) for i, s in enumerate(seeds)]
+
+    def clock():
+        now[0] += 0.05          # every look at the clock costs 50 ms of fake time
+        return now[0]
+
+    evs = list(serve_stream(model=model, codec=codec, requests=iter(reqs), max_batch=3, step_frames=step,
+                            first_chunk_frames=first, chunk_frames=chunk, chunk_growth=growth, clock=clock,
+                            wait=lambda dt: now.__setitem__(0, now[0] + dt)))
+    got = collect(evs, codec.frame_length)
+    finals = [e.rid for e in evs if e.kind == "final"]
+    assert sorted(finals) == [r.rid for r in reqs] and not model.slots and len(model.released) == 9 and len(set(model.released)) >= 2
+    for r, seed, lim in zip(reqs, seeds, limits):
+        want = model.expected_codes(seed, lim if lim else 10 ** 6)
+        audio, codes = got.get(r.rid, (torch.zeros(0), None))
+        if want.shape[1] == 0:
+            assert codes is None or codes.shape[1] == 0
+            continue
+        assert torch.equal(codes, want), r.rid
+        assert torch.equal(audio, codec.from_indices(want[None])[0, 0]), r.rid
+        firsts = [e for e in evs if e.rid == r.rid and e.first_audio_latency is not None]
+        assert len(firsts) == 1 and firsts[0].t0 == 0 and firsts[0].first_audio_latency > 0
+        segs = [e for e in evs if e.rid == r.rid and e.kind == "segment"]
+        assert [e.t0 for e in segs[1:]] == [e.t1 for e in segs[:-1]]                 # gapless, in order
+    ids = {}
+    for (T, t0, sid) in codec.calls:
+        ids.setdefault(sid, []).append((t0, T))
+    assert len(ids) == sum(1 for r in reqs if r.rid in got)                          # one codec stream per utterance
+    assert all(v == sorted(v) and v[0][0] == 0 for v in ids.values())
 
 
 def test_generate_stream_argument_errors():

@@ -392,6 +392,52 @@ def test_continuous_batching_queue_is_schedule_invariant(tiny_model):
     assert stats["frames_run"] >= max(lengths) - 1
 
 
+def test_serve_stream_streams_and_refills_and_equals_the_offline_path(tiny_model, small_codec):
+    """serving.serve_stream (configs 4 + 5 together): nine ragged requests through three slots, each on its own chunk
+    schedule, slots refilled as utterances end by <|im_end|> or max_new_tokens.  Per utterance the concatenated
+    segments are exactly `generate` + `from_indices` of that utterance alone (codes equal, audio bit-identical) --
+    whatever slot, neighbours and chunk boundaries it got; 20 interleaved codec streams (more than the library parks)
+    stay bit-identical too."""
+    from fish_speech_amd.dual_ar import generate
+    from fish_speech_amd.serving import StreamRequest, collect, serve_stream
+
+    cfg, model = tiny_model
+    ccfg, _, codec = small_codec
+    model.set_ignore_eos(False)
+    prompts = _prompts(cfg, 9, seed=77)
+    seeds = [500 + i for i in range(9)]
+    limits = [30, 12, 30, 40, 5, 30, 2, 30, 1]
+    kw = dict(temperature=0.9, top_p=0.8, top_k=20)
+    alone = [generate(model=model, prompt=p, seed=s, max_new_tokens=m, **kw) for p, s, m in zip(prompts, seeds, limits)]
+    for step, first, chunk in ((8, 8, 32), (1, 1, 1), (5, 2, 7)):
+        reqs = [StreamRequest(prompt=p, max_new_tokens=m, seed=s, rid=i) for i, (p, s, m) in enumerate(zip(prompts, seeds, limits))]
+        evs = list(serve_stream(model=model, codec=codec, requests=reqs, max_batch=3, step_frames=step,
+                                first_chunk_frames=first, chunk_frames=chunk, chunk_growth=1.5, **kw))
+        got = collect(evs, ccfg.frame_length)
+        assert sorted(e.rid for e in evs if e.kind == "final") == list(range(9))
+        for i, p in enumerate(prompts):
+            want = alone[i][1:, p.shape[1]:-1]                                  # inference.py:708
+            if want.shape[1] == 0:
+                assert i not in got or got[i][1] is None or got[i][1].shape[1] == 0
+                continue
+            audio, codes = got[i]
+            assert torch.equal(codes, want), (step, i)
+            assert torch.equal(audio, codec.from_indices(want[None].to(DEV))[0, 0].cpu()), (step, i)
+    # more open codec streams than the library keeps parked (15): the least recently used restart, results unchanged
+    codes = [D.make_codes(ccfg, 1, 24, seed=40 + i).to(DEV) for i in range(20)]
+    full = [codec.from_indices(c.clone()) for c in codes]
+    ids = [codec.new_stream_id() for _ in codes]
+    parts = [[] for _ in codes]
+    t0 = 0
+    for t1 in (5, 13, 24):
+        for i, c in enumerate(codes):
+            parts[i].append(codec.from_indices_tail(c[:, :, :t1].clone(), t0, stream_id=ids[i]))
+        t0 = t1
+    for i in range(20):
+        assert torch.equal(torch.cat(parts[i], -1), full[i]), i
+    codec.stream_reset()
+
+
 # ------------------------------------------------------------------------------- 8f #3 / #4: server batch helpers, engine
 
 

@@ -17,7 +17,7 @@ for T in Ts:
     bench.PROMPT_T = T
     prompts = bench.make_prompts(cfg, 8, 1000)
     sp = [model._sampling(0.7, 0.7, 30, 4242 + i, True) for i in range(8)]
-    for impl in (1, 0):
+    for impl in [int(v) for v in os.environ.get("ATTN_IMPLS", "1,0").split(",")]:
         model.set_attn_impl(impl)
         ts = []
         for it in range(4):
