@@ -423,6 +423,40 @@ def run_config5(model, codec, cfg, device, runs=5, first=8, chunk=32):
             "stream_audio_sec_per_s_growing_chunks": round(BATCH * rs[0][2] / SAMPLE_RATE / grow, 2)}
 
 
+def run_config5_staggered(model, codec, cfg, n_req=16, gap_s=0.12):
+    """Configs 4 + 5 together (serving.serve_stream): requests ARRIVE over time (one every gap_s), 8 slots, every
+    utterance streamed on its own chunk schedule, slots refilled as utterances finish.  Reports first-audio latency
+    from arrival (p50 / p90 over the requests, queueing for a slot included) and whole-run throughput."""
+    import statistics
+
+    from fish_speech_amd.serving import StreamRequest, serve_stream
+
+    prompts = make_prompts(cfg, n_req, 7000)
+
+    def once():
+        reqs = [StreamRequest(prompt=p, max_new_tokens=N_FRAMES + 1, seed=8000 + i, rid=i, arrival=i * gap_s)
+                for i, p in enumerate(prompts)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first, samples = {}, 0
+        for ev in serve_stream(model=model, codec=codec, requests=reqs, max_batch=BATCH, step_frames=8,
+                               first_chunk_frames=8, chunk_frames=32, chunk_growth=2.0, temperature=0.7, top_p=0.7, top_k=30):
+            if ev.kind == "segment":
+                torch.cuda.synchronize()
+                samples += ev.audio.shape[-1]
+                if ev.first_audio_latency is not None:
+                    first[ev.rid] = time.perf_counter() - t0 - ev.rid * gap_s
+        return sorted(first.values()), samples, time.perf_counter() - t0
+
+    once()
+    lat, samples, wall = once()
+    return {"workload": f"configs[3]+[4]: {n_req} requests arriving every {int(gap_s * 1e3)} ms, {BATCH} slots, per-utterance "
+                        f"streaming (first chunk 8 frames, then 32, 64, ...) with slot refill (serving.serve_stream)",
+            "first_audio_ms_p50": round(statistics.median(lat) * 1e3, 1),
+            "first_audio_ms_p90": round(lat[int(0.9 * (len(lat) - 1))] * 1e3, 1),
+            "audio_sec_per_s": round(samples / SAMPLE_RATE / wall, 2), "wall_s": round(wall, 3)}
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     import socket
@@ -596,6 +630,7 @@ def main():
         if world == 1 and codec is not None:
             extras["config1_batch1_greedy"] = run_config1(model, codec, cfg, device)
             extras["config4_streaming"] = run_config5(model, codec, cfg, device)
+            extras["config4_streaming_staggered_arrivals"] = run_config5_staggered(model, codec, cfg)
         out["other_configs"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, state, codec_state)

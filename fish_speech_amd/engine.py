@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from .prompt import Conversation, Message, TextPart, VQPart
+from .reference_loader import ReferenceLoader, VQManager
 from .stream import generate_stream
 from .text2semantic import _system_message, group_turns_into_batches, split_text_by_speaker
 
@@ -53,8 +54,11 @@ class TTSRequest:
     temperature: float = 0.8
     chunk_length: int = 200
     seed: Optional[int] = None
-    prompt_texts: Sequence[str] = ()
-    prompt_tokens: Sequence[torch.Tensor] = ()      # (num_codebooks, n) codes of the references (VQManager.encode_reference)
+    reference_id: Optional[str] = None              # references/<id>/*.wav + .lab (ReferenceLoader.load_by_id)
+    references: Sequence = ()                       # ServeReferenceAudio-like objects: .audio (wav bytes), .text
+    use_memory_cache: Literal["on", "off"] = "off"
+    prompt_texts: Sequence[str] = ()                # already-encoded references (extension; used when neither of
+    prompt_tokens: Sequence[torch.Tensor] = ()      # the two above is given): texts + (num_codebooks, n) codes
     top_k: int = 30
     first_chunk_frames: int = 8
     chunk_frames: int = 32
@@ -62,8 +66,11 @@ class TTSRequest:
     max_chunk_frames: int = 256
 
 
-class StreamingTTSEngine:
+class StreamingTTSEngine(ReferenceLoader, VQManager):
+    """TTSInferenceEngine(ReferenceLoader, VQManager) (inference_engine/__init__.py:22-37) over MiDualAR + MiDAC."""
+
     def __init__(self, model, codec, precision=torch.bfloat16):
+        super().__init__()
         self.model, self.decoder_model, self.precision = model, codec, precision
 
     @torch.no_grad()
@@ -81,9 +88,15 @@ class StreamingTTSEngine:
         try:
             if req.streaming:
                 yield InferenceResult("header", (sample_rate, np.array(wav_chunk_header(sample_rate=sample_rate))), None)
-            use_prompt = bool(req.prompt_texts) and bool(req.prompt_tokens)
-            system = _system_message(list(req.prompt_texts) if use_prompt else None,
-                                     [c.cpu() for c in req.prompt_tokens] if use_prompt else None)
+            # references by id or by content hash, encoded by the codec and cached (inference_engine/__init__.py:47-56)
+            prompt_tokens, prompt_texts = list(req.prompt_tokens), list(req.prompt_texts)
+            if req.reference_id is not None:
+                prompt_tokens, prompt_texts = self.load_by_id(req.reference_id, req.use_memory_cache)
+            elif req.references:
+                prompt_tokens, prompt_texts = self.load_by_hash(list(req.references), req.use_memory_cache)
+            use_prompt = bool(prompt_texts) and bool(prompt_tokens)
+            system = _system_message(list(prompt_texts) if use_prompt else None,
+                                     [c.cpu() for c in prompt_tokens] if use_prompt else None)
             turns = split_text_by_speaker(req.text)
             chunks = group_turns_into_batches(turns, max_speakers=5, max_bytes=req.chunk_length) if turns else [req.text]
             history = Conversation([system])

@@ -1,0 +1,180 @@
+"""Reference-audio side of the inference engine: `ReferenceLoader` (fish_speech/inference_engine/reference_loader.py:23-99
+-- references by id from `references/<id>/` or by content hash, with the two in-memory caches) and `VQManager`
+(fish_speech/inference_engine/vq_manager.py:16-53 -- `encode_reference`, `decode_vq_tokens`) over a `MiDAC`.
+
+Same method names, arguments, cache keys, validation and error types as upstream; what differs is audio I/O:
+torchaudio is not in this image, so `load_audio` reads wav bytes / files with scipy and resamples with a polyphase
+filter (host plumbing outside the hot path; mp3 / flac / ... references raise a clear error instead of being
+mis-decoded).  `engine.StreamingTTSEngine` inherits both, like `TTSInferenceEngine` does."""
+from __future__ import annotations
+
+import io
+import re
+import shutil
+from hashlib import sha256
+from pathlib import Path
+from typing import Callable, List, Literal, Tuple
+
+import numpy as np
+import torch
+
+AUDIO_EXTENSIONS = {".mp3", ".wav", ".flac", ".ogg", ".m4a", ".wma", ".aac", ".aiff", ".aif", ".aifc"}   # utils/file.py:8-19
+_ID_PATTERN = re.compile(r"^[a-zA-Z0-9\-_ ]+$")          # reference_loader.py:20
+
+
+def list_files(path, extensions=AUDIO_EXTENSIONS, recursive=False, sort=True) -> List[Path]:
+    """utils/file.py:57-90."""
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(f"Directory {path} does not exist.")
+    files = [f for f in (path.rglob("*") if recursive else path.glob("*")) if f.is_file() and f.suffix in extensions]
+    return sorted(files) if sort else files
+
+
+def audio_to_bytes(file_path):
+    """utils/file.py:41-46."""
+    if not file_path or not Path(file_path).exists():
+        return None
+    with open(file_path, "rb") as f:
+        return f.read()
+
+
+def read_ref_text(ref_text):
+    """utils/file.py:49-54."""
+    path = Path(ref_text)
+    if path.exists() and path.is_file():
+        return path.read_text(encoding="utf-8")
+    return ref_text
+
+
+class VQManager:
+    """vq_manager.py:9-53 on a MiDAC (`self.decoder_model`)."""
+
+    decoder_model = None
+    load_audio: Callable
+
+    def decode_vq_tokens(self, codes):
+        return self.decoder_model.from_indices(codes[None])[0].squeeze()        # vq_manager.py:20
+
+    def encode_reference(self, reference_audio, enable_reference_audio):
+        if not (enable_reference_audio and reference_audio is not None):
+            return None
+        sample_rate = self.decoder_model.sample_rate
+        content = self.load_audio(reference_audio, sample_rate)
+        audios = torch.from_numpy(content).to(self.decoder_model.device)[None, None, :]
+        audio_lengths = torch.tensor([audios.shape[2]], device=self.decoder_model.device, dtype=torch.long)
+        return self.decoder_model.encode(audios, audio_lengths)[0][0]          # vq_manager.py:44
+
+
+class ReferenceLoader:
+    """reference_loader.py:23-260.  `references_root` (default "references", relative to the working directory like
+    upstream) is the only addition: tests point it at a temporary directory."""
+
+    references_root = Path("references")
+
+    def __init__(self) -> None:
+        self.ref_by_id: dict = {}
+        self.ref_by_hash: dict = {}
+
+    @staticmethod
+    def _validate_id(id: str) -> None:
+        if not _ID_PATTERN.match(id) or len(id) > 255:
+            raise ValueError("Reference ID contains invalid characters or is too long. "
+                             "Only alphanumeric, hyphens, underscores, and spaces are allowed.")
+
+    def load_by_id(self, id: str, use_cache: Literal["on", "off"]) -> Tuple:
+        self._validate_id(id)
+        ref_folder = Path(self.references_root) / id
+        ref_folder.mkdir(parents=True, exist_ok=True)
+        ref_audios = list_files(ref_folder, AUDIO_EXTENSIONS, recursive=True, sort=False)
+        if use_cache == "off" or id not in self.ref_by_id:
+            prompt_tokens = [self.encode_reference(reference_audio=audio_to_bytes(str(a)), enable_reference_audio=True)
+                             for a in ref_audios]
+            prompt_texts = [read_ref_text(str(a.with_suffix(".lab"))) for a in ref_audios]
+            self.ref_by_id[id] = (prompt_tokens, prompt_texts)
+        else:
+            prompt_tokens, prompt_texts = self.ref_by_id[id]
+        return prompt_tokens, prompt_texts
+
+    def load_by_hash(self, references: list, use_cache: Literal["on", "off"]) -> Tuple:
+        """references: objects with `.audio` (bytes) and `.text` (ServeReferenceAudio)."""
+        hashes = [sha256(ref.audio).hexdigest() for ref in references]
+        prompt_tokens, prompt_texts = [], []
+        for h, ref in zip(hashes, references):
+            if use_cache == "off" or h not in self.ref_by_hash:
+                prompt_tokens.append(self.encode_reference(reference_audio=ref.audio, enable_reference_audio=True))
+                prompt_texts.append(ref.text)
+                self.ref_by_hash[h] = (prompt_tokens[-1], ref.text)
+            else:
+                tok, text = self.ref_by_hash[h]
+                prompt_tokens.append(tok)
+                prompt_texts.append(text)
+        return prompt_tokens, prompt_texts
+
+    def load_audio(self, reference_audio, sr: int) -> np.ndarray:
+        """bytes or a path -> mono float32 samples at `sr` (reference_loader.py:125-146, torchaudio replaced)."""
+        from scipy.io import wavfile
+        from scipy.signal import resample_poly
+
+        if isinstance(reference_audio, (bytes, bytearray)) or len(reference_audio) > 255 or not Path(reference_audio).exists():
+            src = io.BytesIO(reference_audio if isinstance(reference_audio, (bytes, bytearray)) else bytes(reference_audio))
+        else:
+            src = str(reference_audio)
+        try:
+            original_sr, data = wavfile.read(src)
+        except ValueError as e:
+            raise ValueError("only RIFF/WAVE reference audio can be decoded without torchaudio "
+                             f"(scipy.io.wavfile: {e})") from e
+        x = data.astype(np.float32)
+        if np.issubdtype(data.dtype, np.integer):
+            x /= float(np.iinfo(data.dtype).max)
+        if x.ndim == 2:
+            x = x.mean(axis=1)
+        if original_sr != sr:
+            g = int(np.gcd(int(original_sr), int(sr)))
+            x = resample_poly(x, sr // g, original_sr // g).astype(np.float32)
+        return np.ascontiguousarray(x.squeeze(), dtype=np.float32)
+
+    def list_reference_ids(self) -> List[str]:
+        base = Path(self.references_root)
+        if not base.exists():
+            return []
+        out = []
+        for d in base.iterdir():
+            if not d.is_dir():
+                continue
+            audio = list_files(d, AUDIO_EXTENSIONS, recursive=False, sort=False)
+            if any(a.with_suffix(".lab").exists() for a in audio):
+                out.append(d.name)
+        return sorted(out)
+
+    def add_reference(self, id: str, wav_file_path: str, reference_text: str) -> None:
+        self._validate_id(id)
+        ref_dir = Path(self.references_root) / id
+        if ref_dir.exists():
+            raise FileExistsError(f"Reference ID '{id}' already exists")
+        audio_path = Path(wav_file_path)
+        if not audio_path.exists():
+            raise FileNotFoundError(f"Audio file not found: {wav_file_path}")
+        if audio_path.suffix.lower() not in AUDIO_EXTENSIONS:
+            raise ValueError(f"Unsupported audio format: {audio_path.suffix}. Supported formats: {', '.join(AUDIO_EXTENSIONS)}")
+        try:
+            ref_dir.mkdir(parents=True, exist_ok=False)
+            shutil.copy2(audio_path, ref_dir / f"sample{audio_path.suffix}")
+            (ref_dir / "sample.lab").write_text(reference_text, encoding="utf-8")
+            self.ref_by_id.pop(id, None)
+        except Exception:
+            if ref_dir.exists():
+                shutil.rmtree(ref_dir)
+            raise
+
+    def delete_reference(self, id: str) -> None:
+        self._validate_id(id)
+        ref_dir = Path(self.references_root) / id
+        if not ref_dir.exists():
+            raise FileNotFoundError(f"Reference ID '{id}' does not exist")
+        try:
+            shutil.rmtree(ref_dir)
+            self.ref_by_id.pop(id, None)
+        except Exception as e:
+            raise OSError(f"Failed to delete reference '{id}': {e}")

@@ -213,6 +213,69 @@ def test_serve_stream_refills_slots_and_every_utterance_equals_its_offline_resul
     assert all(v == sorted(v) and v[0][0] == 0 for v in ids.values())
 
 
+def test_reference_loader_and_vq_manager_mirror_the_reference_semantics(tmp_path):
+    """inference_engine/reference_loader.py:23-260 + vq_manager.py:16-53 over a codec object: references by id (a
+    folder of wav + .lab pairs) and by content hash, both caches, id validation, add / list / delete, and the engine
+    resolving `reference_id` / `references` the way TTSInferenceEngine.inference does."""
+    import io
+    from types import SimpleNamespace
+
+    from scipy.io import wavfile
+
+    from fish_speech_amd.engine import StreamingTTSEngine, TTSRequest
+    from fish_speech_amd.reference_loader import ReferenceLoader
+
+    class Codec(StubCodec):                      # the stub model counts NCB codebooks: encode as many rows
+        def encode(self, padded, audio_lengths=None):
+            feats, lens = super().encode(padded, audio_lengths)
+            return feats[:, :NCB], lens
+
+    codec = Codec()
+    eng = StreamingTTSEngine(StubDualAR(max_batch=1), codec, precision=None)
+    eng.references_root = tmp_path / "references"
+    sr = codec.sample_rate
+    t = np.arange(sr // 10) / sr
+    a = (0.3 * np.sin(2 * np.pi * 200 * t)).astype(np.float32)
+    src = tmp_path / "voice.wav"
+    wavfile.write(str(src), sr // 2, a[::2].copy())                    # half the rate: load_audio resamples
+    with pytest.raises(ValueError):
+        eng.load_by_id("../etc", "off")
+    with pytest.raises(FileNotFoundError):
+        eng.add_reference("alice", str(tmp_path / "nope.wav"), "x")
+    eng.add_reference("alice", str(src), "hello from alice")
+    with pytest.raises(FileExistsError):
+        eng.add_reference("alice", str(src), "again")
+    assert eng.list_reference_ids() == ["alice"]
+    toks, texts = eng.load_by_id("alice", "on")
+    assert texts == ["hello from alice"] and len(toks) == 1 and toks[0].shape[0] == NCB
+    n_frames = -(-(len(a[::2]) * 2) // codec.frame_length)
+    assert abs(toks[0].shape[1] - n_frames) <= 1                         # resampled back to the codec's rate
+    again, _ = eng.load_by_id("alice", "on")
+    assert again[0] is toks[0]                                           # cache hit: the very same tensor
+    fresh, _ = eng.load_by_id("alice", "off")
+    assert fresh[0] is not toks[0] and torch.equal(fresh[0], toks[0])
+    buf = io.BytesIO()
+    wavfile.write(buf, sr, a)
+    ref = SimpleNamespace(audio=buf.getvalue(), text="by hash")
+    t1, x1 = eng.load_by_hash([ref, ref], "on")
+    assert x1 == ["by hash", "by hash"] and t1[1] is t1[0] and len(eng.ref_by_hash) == 1
+    with pytest.raises(ValueError):
+        eng.load_audio(b"not a wav file at all", sr)
+    assert eng.encode_reference(None, True) is None and eng.encode_reference(buf.getvalue(), False) is None
+    wav = eng.decode_vq_tokens(t1[0])
+    assert wav.dim() == 1 and wav.shape[0] == t1[0].shape[1] * codec.frame_length
+    # the engine resolves the request's references through the loader before building the prompt
+    res = list(eng.inference(TTSRequest(text="hi", reference_id="alice", use_memory_cache="on", max_new_tokens=8, seed=3)))
+    assert res[-1].code == "final"
+    res = list(eng.inference(TTSRequest(text="hi", references=[ref], max_new_tokens=8, seed=3)))
+    assert res[-1].code == "final"
+    eng.delete_reference("alice")
+    assert eng.list_reference_ids() == [] and "alice" not in eng.ref_by_id
+    with pytest.raises(FileNotFoundError):
+        eng.delete_reference("alice")
+    assert isinstance(eng, ReferenceLoader)
+
+
 def test_generate_stream_argument_errors():
     model, codec = StubDualAR(max_batch=2, max_seq_len=64), StubCodec()
     p = torch.zeros(NCB + 1, 5, dtype=torch.int64)

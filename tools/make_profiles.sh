@@ -37,6 +37,27 @@ CSV=$(find "$W/pmc" -name '*counter_collection.csv' | head -1)
 { echo "# rocprofv3 --pmc FETCH_SIZE --kernel-trace over bench.py --frames 12 --steps 1 --warmup 0 --no-codec (libfishmi.so sha1 $SHA, tree $HEAD)";
   python tools/pmc_traffic.py "$CSV" 12 "$OUT/pmc_traffic.json"; } > "$OUT/${TAG}_pmc_fetch_decode.txt" 2>&1
 
+# decode attention at long contexts: one kernel-trace run per context length
+{ echo "# attn_decode_fused_kernel (VALU, K/V rows streamed from the paged cache) at B = 8, S2-Pro shape: tools/attn_decode_probe.py T under rocprofv3 --kernel-trace --stats";
+  echo "# libfishmi.so sha1 $SHA, tree $HEAD; bytes per launch = 32768 x S; 'GB/s' = bytes / avg duration"; } > "$OUT/${TAG}_attn_decode.txt"
+for T in 300 1024 2048; do
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$W/attn$T" -o a -- python "$R/tools/attn_decode_probe.py" $T ) > "$OUT/attn${T}_run.log" 2>&1
+  db=$(find "$W/attn$T" -name '*_results.db' | head -1)
+  grep -h "^T=" "$OUT/attn${T}_run.log" >> "$OUT/${TAG}_attn_decode.txt"
+  python - "$db" $T >> "$OUT/${TAG}_attn_decode.txt" <<'PY'
+import sqlite3, sys
+db, T = sys.argv[1], int(sys.argv[2])
+cur = sqlite3.connect(db).cursor()
+rows = list(cur.execute("select name, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where name like '%attn_decode_fused%' or name like '%linear_skinny%' group by name order by 3*count(*) desc limit 6"))
+for name, n, avg, mn in rows:
+    extra = ""
+    if "attn_decode" in name:
+        b = 32768 * (T + 10)
+        extra = f"   <- {b / 1e6:.1f} MB per launch = {b / avg / 1e3:.0f} GB/s"
+    print(f"  {avg:8.2f} us avg ({mn:.2f} min) x{n:5d}  {name[:90]}{extra}")
+PY
+done
+
 # timing-only runs (no profiler): streaming breakdown + latency
 python tools/stream_breakdown.py > "$OUT/${TAG}_stream_breakdown.txt" 2>&1
 python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt" 2>&1
