@@ -282,9 +282,6 @@ class MiDAC:
     def eval(self):
         return self
 
-    def to(self, *a, **k):
-        return self
-
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -32,8 +32,13 @@ def main(path, n_frames, out_json=None):
         k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"]) * 1024 * 2
-    n_decode = n_frames - 1
-    print(f"# {path}: {n_frames} frames (1 prefill frame + {n_decode} graph-replayed decode frames)")
+    # frames of the pass, counted from the launches themselves: one embed launch per frame, over the prompt rows for a
+    # prefill frame (hundreds of work-groups), over the batch for a decode frame
+    n_prefill = sum(n for (name, wgs), (n, _) in agg.items() if "embed_kernel" in name and wgs > 64)
+    n_decode = sum(n for (name, wgs), (n, _) in agg.items() if "embed_kernel" in name and wgs <= 64)
+    if n_prefill + n_decode == 0:
+        n_prefill, n_decode = 1, n_frames - 1
+    print(f"# {path}: {n_prefill} prefill frame(s) + {n_decode} graph-replayed decode frames (bench --frames {n_frames})")
     print(f"{'calls':>7} {'avg MB/launch':>14}  kernel [work-groups]")
     frame_bytes = 0.0
     for (name, wgs), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -43,11 +48,12 @@ def main(path, n_frames, out_json=None):
             frame_bytes += v
     # the prefill frame runs the same tail (fast chain + heads) once; slow layers there use the tiled path
     print(f"\nHBM bytes fetched by the decode-frame kernels: {frame_bytes / 1e9:.3f} GB over the run "
-          f"= {frame_bytes / (n_decode + 0.52) / 1e9:.3f} GB per decode frame "
-          f"(prefill-frame tail counted as 0.52 frame: the fast chain and the heads of a frame)")
+          f"= {frame_bytes / (n_decode + 0.52 * n_prefill) / 1e9:.3f} GB per decode frame "
+          f"(a prefill frame's tail counted as 0.52 frame: the fast chain and the heads of a frame)")
     if out_json:
         with open(out_json, "w") as f:
-            json.dump({"bytes_per_decode_frame": round(frame_bytes / (n_decode + 0.52)), "batch": 8, "frames_in_pass": n_frames,
+            json.dump({"bytes_per_decode_frame": round(frame_bytes / (n_decode + 0.52 * n_prefill)), "batch": 8,
+                       "decode_frames_in_pass": n_decode, "prefill_frames_in_pass": n_prefill,
                        "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace over `bench.py --frames %d --steps 1 --warmup 0 "
                                  "--no-codec --no-extras --no-cpu-baseline` (tools/make_profiles.sh), summed over the decode-frame "
                                  "kernels by tools/pmc_traffic.py: KiB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)" % n_frames},
