@@ -5,6 +5,9 @@
 # Kernel timings (--kernel-trace --stats) and PMC counters (--pmc) are collected in SEPARATE rocprofv3 runs.
 set -u
 TAG=${1:-r03}
+shift || true
+SECTIONS=${*:-step codec prefill pmc attn stream}      # optional: only these sections
+want() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles_$TAG
@@ -23,21 +26,24 @@ run_stats() {  # name, header, command...
 }
 
 R=$PWD
-run_stats step "python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline under rocprofv3 --kernel-trace --stats" \
+want step && run_stats step "python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline under rocprofv3 --kernel-trace --stats" \
   python "$R/bench.py" --steps 2 --warmup 1 --no-extras --no-cpu-baseline
-run_stats codec "tools/codec_bench.py (B=8, T=215, fp16-split default + encode) under rocprofv3 --kernel-trace --stats" \
+want codec && run_stats codec "tools/codec_bench.py (B=8, T=215, fp16-split default + encode) under rocprofv3 --kernel-trace --stats" \
   env PLANES=2 python "$R/tools/codec_bench.py"
-run_stats prefill "tools/prefill_bench.py 200 2048 (S2-Pro shape, 8 prompts) under rocprofv3 --kernel-trace --stats" \
+want prefill && run_stats prefill "tools/prefill_bench.py 200 2048 (S2-Pro shape, 8 prompts) under rocprofv3 --kernel-trace --stats" \
   python "$R/tools/prefill_bench.py" 200 2048
 
 # HBM traffic of the decode frame: PMC pass on its own (12 frames: 1 prefill frame + 11 graph-replayed decode frames)
+if want pmc; then
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$W/pmc" -o p -- \
     python "$R/bench.py" --frames 12 --steps 1 --warmup 0 --no-codec --no-extras --no-cpu-baseline ) > "$OUT/pmc_run.log" 2>&1
 CSV=$(find "$W/pmc" -name '*counter_collection.csv' | head -1)
 { echo "# rocprofv3 --pmc FETCH_SIZE --kernel-trace over bench.py --frames 12 --steps 1 --warmup 0 --no-codec (libfishmi.so sha1 $SHA, tree $HEAD)";
   python tools/pmc_traffic.py "$CSV" 12 "$OUT/pmc_traffic.json"; } > "$OUT/${TAG}_pmc_fetch_decode.txt" 2>&1
+fi
 
 # decode attention at long contexts: one kernel-trace run per context length
+if want attn; then
 { echo "# attn_decode_fused_kernel (VALU, K/V rows streamed from the paged cache) at B = 8, S2-Pro shape: tools/attn_decode_probe.py T under rocprofv3 --kernel-trace --stats";
   echo "# libfishmi.so sha1 $SHA, tree $HEAD; bytes per launch = 32768 x S; 'GB/s' = bytes / avg duration"; } > "$OUT/${TAG}_attn_decode.txt"
 for T in 300 1024 2048; do
@@ -57,8 +63,9 @@ for name, n, avg, mn in rows:
     print(f"  {avg:8.2f} us avg ({mn:.2f} min) x{n:5d}  {name[:90]}{extra}")
 PY
 done
+fi
 
 # timing-only runs (no profiler): streaming breakdown + latency
-python tools/stream_breakdown.py > "$OUT/${TAG}_stream_breakdown.txt" 2>&1
-python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt" 2>&1
+want stream && python tools/stream_breakdown.py > "$OUT/${TAG}_stream_breakdown.txt" 2>&1
+want stream && python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt" 2>&1
 ls -la "$OUT"

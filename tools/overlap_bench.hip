@@ -8,6 +8,9 @@
 //           launches of 256 work-groups are always co-resident (2 x 512 threads per CU), so the wait cannot deadlock;
 //           spins are bounded anyway.
 //   mode 2: as mode 1 without the wait (upper bound: pure overlap, wrong results in a real kernel)
+//   modes 3-5 (round 3): the same three WITHOUT a graph -- eager launches, kernel k on stream k % 2.  Two streams are two
+//           hardware queues, so kernel k may really be resident while k-1 runs (stream order keeps k-2 finished before k
+//           starts: at most two launches co-resident, 2 x 512 threads per CU, no deadlock); the host pays ~4 us per launch.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/overlap_bench.hip -o /tmp/overlap && timeout 120 /tmp/overlap
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -80,7 +83,7 @@ int main(int argc, char** argv) {
   hipEvent_t fork, join, e0, e1;
   CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = (argc > 2 ? 3 : 0); mode < 3; ++mode) {   // (a second argument skips the graph modes)
     hipGraph_t graph; hipGraphExec_t gexec;
     CK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
     CK(hipMemsetAsync(done, 0, n * 4, s0));
@@ -103,6 +106,26 @@ int main(int argc, char** argv) {
       fflush(stdout);
     }
     CK(hipGraphExecDestroy(gexec)); CK(hipGraphDestroy(graph));
+  }
+  for (int mode = 3; mode < 6; ++mode) {   // eager: 3 = one stream, 4 = two streams + completion-counter wait, 5 = two streams, no wait
+    for (int rep = 0; rep < 4; ++rep) {
+      CK(hipMemsetAsync(done, 0, n * 4, s0));
+      CK(hipMemsetAsync(err, 0, 4, s0));
+      CK(hipStreamSynchronize(s0)); CK(hipStreamSynchronize(s1));
+      CK(hipEventRecord(e0, s0));
+      if (mode > 3) { CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0)); }
+      for (int k = 0; k < n; ++k) {
+        hipStream_t st = (mode > 3 && (k & 1)) ? s1 : s0;
+        hipLaunchKernelGGL(gemv_like, dim3(nwg), dim3(512), 0, st, w + segs[k].off16, segs[k].n16_per_wg, x, segs[k].xn16, done, k,
+                           mode == 4 ? 1 : 0, sink, err);
+      }
+      if (mode > 3) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
+      CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      unsigned herr = 0; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+      if (rep) printf("mode %d (eager): %8.3f ms  %7.1f GB/s  %.2f us per launch%s\n", mode, ms, bytes / ms * 1e-6, ms * 1e3 / n, herr ? "  ** SPIN CAP HIT **" : "");
+      fflush(stdout);
+    }
   }
   return 0;
 }
