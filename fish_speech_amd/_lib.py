@@ -75,6 +75,7 @@ _SIGS = {
     "fmi_dualar_set_trace": (C.c_int, [_P, _I, C.POINTER(_P)]),
     "fmi_dualar_set_graph": (C.c_int, [_P, _I]),
     "fmi_dualar_set_attn_impl": (C.c_int, [_P, _I]),
+    "fmi_dualar_set_attn_long_threshold": (C.c_int, [_P, _I]),
     "fmi_dualar_set_ignore_eos": (C.c_int, [_P, _I]),
     "fmi_dualar_last_decode_stats": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "fmi_op_linear_int8": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_float, _I, _I, _P]),

@@ -82,6 +82,14 @@ struct fmi_dualar {
   bool trace = false, use_graph = true, ignore_eos = false;
   bool force_tiled = false;
   int attn_impl = 1;   // prefill attention: 1 = MFMA flash kernel with LDS-staged K/V tiles, 0 = VALU kernel (A/B parity)
+  // decode attention: rows at or beyond this position run on the MFMA kernel + merge (launch_attn_decode_long), the
+  // others on the fused VALU kernel; 0 = VALU for every row.  FMI_ATTN_THR overrides, fmi_dualar_set_attn_long_threshold
+  // sets.  Which kernels a frame launches (attn_mask: 1 = VALU, 2 = MFMA) follows from the host's view of the slots'
+  // positions (pos_host: exact for live slots, an over-estimate for finished ones, whose outputs nobody reads).
+  int attn_long_thr = 1024;   // measured break-even at B = 8 (profiles/r03_attn_decode.txt): 19.2 vs 19.0 us at 1 k keys, 24.1 vs 32.3 at 2 k
+  int attn_mask = 1;
+  std::vector<int> pos_host;
+  float* attn_part = nullptr;
   int max_top_k = 0;  // largest top_k over the LIVE slots (selects the sampler variant the graphs embed)
   std::vector<int> slot_top_k;  // per slot, 0 = released
   std::map<int, hipGraphExec_t> graphs;
@@ -307,9 +315,17 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
   a.rope = h->rope; a.row_slot = row_slot; a.row_pos = row_pos; a.block_table = h->st.block_table;
   a.slot_pos = h->st.pos; a.slot_done = row_pos == nullptr ? h->st.done : nullptr; a.max_pages = h->max_pages; a.rows = rows; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
   a.eps = h->cfg.norm_eps;
-  if (row_pos == nullptr) {  // decode: one row per slot -> fused prep + attention
-    FMI_CHECK(launch_attn_decode_fused(a, s));
-    h->launches += 1;
+  if (row_pos == nullptr) {  // decode: one row per slot -> fused prep + attention, by the row's own context length
+    a.part = h->attn_part;
+    a.long_thr = (h->attn_mask & 2) ? h->attn_long_thr : 0;
+    if (h->attn_mask & 1) {
+      FMI_CHECK(launch_attn_decode_fused(a, s));
+      h->launches += 1;
+    }
+    if (h->attn_mask & 2) {
+      FMI_CHECK(launch_attn_decode_long(a, s));
+      h->launches += 2;
+    }
   } else {
     FMI_CHECK(launch_attn_prep(a, s));
     a.qtiles = ws.qtiles; a.n_qtiles = ws.n_qtiles;
@@ -493,6 +509,7 @@ int reserve_pages(fmi_dualar* h, int slot, int upto_pos_exclusive) {
 
 int set_slot(fmi_dualar* h, int slot, int pos, int frame, int limit, const fmi_sampling& sp, bool zero_window) {
   hipStream_t s = h->stream;
+  h->pos_host[slot] = pos;
   h->slot_top_k[slot] = (int)sp.top_k;
   int mk = 0;
   for (int k : h->slot_top_k) mk = std::max(mk, k);
@@ -585,7 +602,7 @@ void fmi_dualar_destroy(fmi_dualar* h) {
   void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
                   h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
                   h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging, h->staging2,
-                  h->qkv0_tab, h->qkv0_pre};
+                  h->qkv0_tab, h->qkv0_pre, h->attn_part};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (void* p : h->row_copies) hipFree(p);
@@ -846,7 +863,14 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
   for (int p = h->n_pages - 1; p >= 0; --p) h->free_pages.push_back(p);
   h->slot_pages.assign(max_batch, {});
   h->slot_top_k.assign(max_batch, 0);
+  h->pos_host.assign(max_batch, 0);
   h->max_top_k = 0;
+  {
+    static const int env_thr = []() { const char* e = getenv("FMI_ATTN_THR"); return e ? atoi(e) : -1; }();
+    if (env_thr >= 0) h->attn_long_thr = env_thr;
+    if (!attn_decode_long_supported(s.H, s.KVH, s.D)) h->attn_long_thr = 0;
+    if (h->attn_long_thr > 0) FMI_CHECK(dev_alloc(&h->attn_part, attn_decode_long_part_floats(max_batch, s.H, s.D)));
+  }
   return ensure_rows(h, max_batch);
 }
 
@@ -972,9 +996,23 @@ int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frame
     FMI_CHECK_HIP(hipStreamSynchronize(s));
     h->row_slot_host.assign(slot_ids, slot_ids + n);
   }
+  // which decode-attention kernels the frames of this call need: the VALU kernel if some slot is below the threshold
+  // when the call starts, the MFMA pair if some slot reaches it before the call ends (each row then picks by its own
+  // position; a launch whose rows are all in the other regime returns at once)
+  int mask = 1;
+  if (h->attn_long_thr > 0) {
+    mask = 0;
+    for (int i = 0; i < n; ++i) {
+      const int p = h->pos_host[slot_ids[i]];
+      if (p < h->attn_long_thr) mask |= 1;
+      if (p + n_frames > h->attn_long_thr) mask |= 2;
+    }
+  }
+  h->attn_mask = mask;
   hipGraphExec_t exec = nullptr;
   if (h->use_graph && !h->trace) {
-    auto it = h->graphs.find(n);
+    const int key = n | (mask << 8);
+    auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipGraph_t g = nullptr;
       FMI_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -984,7 +1022,7 @@ int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frame
       FMI_CHECK_HIP(e);
       FMI_CHECK_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
       FMI_CHECK_HIP(hipGraphDestroy(g));
-      h->graphs[n] = exec;
+      h->graphs[key] = exec;
     } else {
       exec = it->second;
     }
@@ -994,6 +1032,8 @@ int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frame
     if (exec) FMI_CHECK_HIP(hipGraphLaunch(exec, s));
     else FMI_CHECK(decode_frame(h, n, s));
   }
+  for (int i = 0; i < n; ++i)
+    h->pos_host[slot_ids[i]] = std::min(h->pos_host[slot_ids[i]] + n_frames, h->max_seq);
   FMI_CHECK_HIP(hipEventRecord(h->ev_t1, s));
   // The caller's stream is NOT made to wait here.  A wait that stays pending on another hardware queue for the length
   // of the frame loop costs every kernel dispatch of that loop (measured, tools/decode_chunk_probe.py: +0.3 ms per frame
@@ -1096,6 +1136,7 @@ int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int po
     if (prev_dev)
       FMI_CHECK_HIP(hipMemcpyAsync(h->st.window + (int64_t)slot * ncb1 * RAS_WIN, prev_dev,
                                    (size_t)ncb1 * RAS_WIN * 4, hipMemcpyDeviceToDevice, s));
+    h->attn_mask = (h->attn_long_thr > 0 && pos0 >= h->attn_long_thr) ? 2 : 1;
     FMI_CHECK(decode_frame(h, 1, s));
   }
   FMI_CHECK_HIP(hipMemcpyAsync(out_dev, h->st.cur + (int64_t)slot * ncb1, ncb1 * 4, hipMemcpyDeviceToDevice, s));
@@ -1126,6 +1167,7 @@ int fmi_dualar_forward_slow(fmi_dualar* h, int slot, const int32_t* x_dev, int S
     h->row_slot_host.clear();
     FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, &slot, 4, hipMemcpyHostToDevice, s));
     FMI_CHECK_HIP(hipStreamSynchronize(s));
+    h->attn_mask = (h->attn_long_thr > 0 && pos0 >= h->attn_long_thr) ? 2 : 1;
     FMI_CHECK(decode_frame(h, 1, s, true));
   }
   if (logits_out_dev)
@@ -1202,6 +1244,16 @@ int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl) {
   FMI_REQUIRE(h, "null handle");
   FMI_REQUIRE(impl == 0 || impl == 1, "attn impl must be 0 (VALU) or 1 (MFMA)");
   h->attn_impl = impl;
+  return FMI_OK;
+}
+
+int fmi_dualar_set_attn_long_threshold(fmi_dualar* h, int threshold) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_REQUIRE(threshold >= 0, "threshold must be >= 0 (0 = VALU kernel for every row)");
+  FMI_REQUIRE(threshold == 0 || h->attn_part, "the MFMA decode attention is not available for this shape / was disabled at setup_caches");
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  drop_graphs(h);
+  h->attn_long_thr = threshold;
   return FMI_OK;
 }
 

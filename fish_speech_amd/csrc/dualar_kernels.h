@@ -117,11 +117,18 @@ struct AttnArgs {
   int max_pages;
   int rows, H, KVH, D;
   float eps;
+  // decode at long contexts: rows whose position is >= long_thr are served by launch_attn_decode_long (MFMA, key ranges
+  // split over work-groups, partial states in `part`), the others by launch_attn_decode_fused; 0 = every row VALU
+  int long_thr;
+  float* part;                // [rows][KVH][ATTN_Z][G][2 + D] fp32 (attn_decode_long_part_floats)
 };
 int launch_attn_prep(const AttnArgs& a, hipStream_t s);
 int launch_attn(const AttnArgs& a, hipStream_t s);               // VALU kernel (kept for A/B parity runs)
 int launch_attn_prefill_mfma(const AttnArgs& a, hipStream_t s);  // MFMA flash attention over the query tiles
-int launch_attn_decode_fused(const AttnArgs& a, hipStream_t s);  // one row per slot only
+int launch_attn_decode_fused(const AttnArgs& a, hipStream_t s);  // one row per slot only (rows below a.long_thr if that is set)
+bool attn_decode_long_supported(int H, int KVH, int D);
+int64_t attn_decode_long_part_floats(int rows, int H, int D);
+int launch_attn_decode_long(const AttnArgs& a, hipStream_t s);   // rows at or beyond a.long_thr: MFMA kernel + merge
 
 struct FastAttnArgs {
   const bf16_t* qkv;   // [B][(H+2KVH)*D]

@@ -1479,6 +1479,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = a.row_slot[r];
   const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
+  if (a.long_thr > 0 && pos >= a.long_thr) return;   // this row is served by attn_decode_mfma_kernel + merge
   const int H = a.H, KVH = a.KVH, Gt = H / KVH;
   const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
   const bf16_t* src = a.qkv + (int64_t)r * (H + 2 * KVH) * D;
@@ -1656,6 +1657,310 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
   }
 }
 
+// =====================================================================================
+// decode attention at LONG contexts on MFMA (round 3): rows whose position is >= AttnArgs::long_thr
+// =====================================================================================
+//
+// Measured (profiles/r03_attn_decode*.txt): the VALU kernel above is latency-bound at the benchmark's context (~300 keys,
+// 8.9 us) but bound by per-key VALU work at voice-clone lengths (32 us at 2 k keys = 2.1 TB/s; fewer, fatter
+// work-groups and deeper prefetch both lose).  Here the per-key arithmetic is on the matrix cores:
+//
+//   attn_decode_mfma_kernel   grid (rows, KVH, ATTN_Z), 4 waves.  The work-group owns one utterance, one kv head --
+//     all G query heads at once, as the first G of the 16 MFMA columns, so K/V are read once per kv head -- and the
+//     z-th of ATTN_Z (= 8) equal ranges of 32-key blocks of the cached keys [0, pos); wave w takes blocks w, w + 4, ... of
+//     that range.  Per block: S^T = K Q^T with the K rows straight from the paged cache as the A operand (a 16-byte
+//     piece per lane IS a fragment: no LDS), fp32 online softmax per column, P stays in registers as the B operand of
+//     O^T += V^T P (bf16 hi + lo, like the prefill kernel), V^T through a per-wave LDS transpose (the cache keeps V
+//     key-major).  The four waves' (m, l, O) states are merged through LDS in wave order, the result goes to a
+//     partials buffer [row][kvh][z][G][2 + D] fp32.
+//   attn_decode_merge_kernel  grid (rows, KVH), 4 waves: q / k head norm + RoPE of the NEW token (as in the VALU
+//     kernel's phase 1), K/V append, the new key's score per head, merge of the ATTN_Z partials and that key, output.
+//
+// Which kernel serves a row depends only on the row's own position (and ATTN_Z and the block ranges only on it too), so
+// an utterance's numbers still do not depend on its batch-mates.  MATH-backend numerics like the prefill kernel: fp32
+// scores, fp32 softmax, fp32 accumulation, one bf16 rounding of the output.
+constexpr int ATTN_Z = 8;
+
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnArgs a) {
+  constexpr int KB = 32, DC = D / 8, NW = 4;
+  constexpr int VROWB = KB * 2 + 8;           // bytes per s_vt row (32 keys + 8 bytes pad)
+  constexpr int VROWS = 8 * (DC + 1);         // permuted row index j*(DC+1) + dchunk
+  constexpr int VCH = (KB / 2) * DC / 64;     // key-pair chunks per lane (D = 128: 4)
+  static_assert(((KB / 2) * DC) % 64 == 0 && G <= NW, "V staging / one wave per query head in phase 1");
+  __shared__ __attribute__((aligned(16))) unsigned char s_vt[NW][VROWS * VROWB];
+  __shared__ __attribute__((aligned(16))) bf16_t s_q[G][D];
+  __shared__ float s_m[NW][16], s_l[NW][16];
+  __shared__ float s_o[NW][G][D];
+
+  const int r = blockIdx.x, kvh = blockIdx.y, z = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int slot = a.row_slot[r];
+  const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
+  if (pos < a.long_thr) return;
+  const int H = a.H, KVH = a.KVH, Gt = H / KVH;
+  const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
+  const bf16_t* src = a.qkv + (int64_t)r * (H + 2 * KVH) * D;
+
+  // ---- this work-group's block range of the cached keys [0, pos)
+  const int nb = (pos + KB - 1) / KB;
+  const int b_lo = (int)((int64_t)z * nb / ATTN_Z), b_hi = (int)((int64_t)(z + 1) * nb / ATTN_Z);
+  f32x4 o[D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -1e30f, l = 0.f;
+  const float scale = 1.0f / sqrtf((float)D);
+  unsigned char* vt = s_vt[wave];
+
+  u32x4 kfr[2][D / 32];       // K fragments of a block: [key tile][k-step], straight from the cache
+  uint4 vreg[VCH][2];
+  auto fetch = [&](int kb) {
+    const int page = bt[(kb * KB) / KV_PAGE];
+    const int64_t pbase = ((int64_t)page * KVH + kvh) * KV_PAGE + (kb * KB) % KV_PAGE;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < D / 32; ++kk)
+        kfr[kt][kk] = *reinterpret_cast<const u32x4*>(a.kpool + (pbase + kt * 16 + c) * D + kk * 32 + g * 8);
+#pragma unroll
+    for (int it = 0; it < VCH; ++it) {
+      const int i = lane + it * 64;
+      const int kp = i / DC, dc = i % DC;
+      // rows at or beyond `pos` have not been written by this utterance (stale pool contents): they must read as 0,
+      // a masked probability of 0 times a stale NaN / Inf would poison the accumulator
+      const bool v0 = kb * KB + 2 * kp < pos, v1 = kb * KB + 2 * kp + 1 < pos;
+      vreg[it][0] = v0 ? *reinterpret_cast<const uint4*>(a.vpool + (pbase + 2 * kp) * D + dc * 8) : make_uint4(0, 0, 0, 0);
+      vreg[it][1] = v1 ? *reinterpret_cast<const uint4*>(a.vpool + (pbase + 2 * kp + 1) * D + dc * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  int kb = b_lo + wave;
+  if (kb < b_hi) fetch(kb);
+  // (the first block's rows are in flight during the query phase: they depend on nothing computed here)
+  // ---- the query heads: norm + RoPE exactly as attn_decode_fused_kernel's phase 1, wave w -> head w
+  if (wave < G) {
+    const int h = kvh * Gt + wave;
+    const bool act = lane < D / 2;
+    const int p = act ? lane : 0;
+    const uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+    const float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
+    float y0 = x0, y1 = x1;
+    if (a.qnw) {
+      const float ss = wave_sum(x0 * x0 + x1 * x1);
+      const float rstd = rsqrtf(ss / (float)D + a.eps);
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.qnw[2 * p])));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.qnw[2 * p + 1])));
+    }
+    const uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+    const float cc = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
+    if (act) {
+      s_q[wave][2 * p] = f2bf(__fsub_rn(__fmul_rn(y0, cc), __fmul_rn(y1, sn)));
+      s_q[wave][2 * p + 1] = f2bf(__fadd_rn(__fmul_rn(y1, cc), __fmul_rn(y0, sn)));
+    }
+  }
+  __syncthreads();
+  // Q^T fragments (B operand): column c = query head c (columns >= G are zero), k rows = d chunk g of k-step kk
+  bf16x8 qf[D / 32];
+#pragma unroll
+  for (int kk = 0; kk < D / 32; ++kk) {
+    qf[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < G) qf[kk] = *reinterpret_cast<const bf16x8*>(&s_q[c][kk * 32 + g * 8]);
+  }
+
+  for (; kb < b_hi; kb += NW) {
+    // ---- V block -> this wave's LDS image, transposed [d][32 keys] (row permutation as in the prefill kernel)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();            // the previous block's reads of `vt` are done (same wave)
+#pragma unroll
+    for (int it = 0; it < VCH; ++it) {
+      const int i = lane + it * 64;
+      const int kp = i / DC, dc = i % DC;
+      const bf16_t* e0 = reinterpret_cast<const bf16_t*>(&vreg[it][0]);
+      const bf16_t* e1 = reinterpret_cast<const bf16_t*>(&vreg[it][1]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<uint32_t*>(&vt[(j * (DC + 1) + dc) * VROWB + kp * 4]) = (uint32_t)e0[j] | ((uint32_t)e1[j] << 16);
+    }
+    // ---- scores: two 16-key tiles, lane (c, g) ends up with keys kt*16 + g*4 + j of query column (head) c
+    f32x4 sacc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      sacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < D / 32; ++kk)
+        sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&kfr[kt][kk]), qf[kk], sacc[kt], 0, 0, 0);
+    }
+    const int kb_cur = kb;
+    if (kb + NW < b_hi) fetch(kb + NW);         // next block's rows in flight during the softmax / PV maths
+    float sc[8];
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kb_cur * KB + kt * 16 + g * 4 + j;
+        const float v = key < pos ? sacc[kt][j] * scale : -1e30f;
+        sc[kt * 4 + j] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float corr = __expf(m - mn);
+    float ps = 0.f, pr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pr[j] = sc[j] > -1e29f ? __expf(sc[j] - mn) : 0.f;
+      ps += pr[j];
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * corr + ps;
+    m = mn;
+    bf16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16_t hi = f2bf(pr[j]);
+      ph[j] = (short)hi;
+      pl[j] = (short)f2bf(pr[j] - bf2f(hi));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();            // the transposed V image is complete (written by this wave's lanes)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+      const int d = dt * 16 + c;
+      const unsigned char* row = &vt[((d & 7) * (DC + 1) + (d >> 3)) * VROWB];
+      const uint2 lo = *reinterpret_cast<const uint2*>(row + g * 8);        // keys g*4 .. g*4+3
+      const uint2 hi = *reinterpret_cast<const uint2*>(row + 32 + g * 8);   // keys 16 + g*4 ..
+      u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+      const bf16x8 vfrag = *reinterpret_cast<bf16x8*>(&av);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] *= corr;
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, ph, o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pl, o[dt], 0, 0, 0);
+    }
+  }
+
+  // ---- merge the four waves (wave order), write the partial state of this key range
+  if (g == 0) {
+    s_m[wave][c] = m;
+    s_l[wave][c] = l;
+  }
+  if (c < G) {
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_o[wave][c][dt * 16 + g * 4 + j] = o[dt][j];
+  }
+  __syncthreads();
+  float* part = a.part + ((((int64_t)r * KVH + kvh) * ATTN_Z + z) * G) * (D + 2);
+  for (int i = tid; i < G * D; i += 256) {
+    const int gq = i / D, d = i % D;
+    float M = -1e30f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][gq]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float wgt = __expf(s_m[w][gq] - M);
+      L += s_l[w][gq] * wgt;
+      O += s_o[w][gq][d] * wgt;
+    }
+    part[gq * (D + 2) + 2 + d] = O;
+    if (d == 0) {
+      part[gq * (D + 2)] = M;
+      part[gq * (D + 2) + 1] = L;
+    }
+  }
+}
+
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(AttnArgs a) {
+  __shared__ float s_q[G][D];
+  __shared__ float s_k[D], s_v[D];
+  __shared__ float s_s[G];
+  const int r = blockIdx.x, kvh = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = a.row_slot[r];
+  const int pos = a.row_pos ? a.row_pos[r] : a.slot_pos[slot];
+  if (pos < a.long_thr) return;
+  const int H = a.H, KVH = a.KVH, Gt = H / KVH;
+  const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
+  const bf16_t* src = a.qkv + (int64_t)r * (H + 2 * KVH) * D;
+  // ---- the new token: k head (norm + RoPE -> cache + LDS), v head (-> cache + LDS), G q heads (norm + RoPE -> LDS);
+  // the same arithmetic as attn_decode_fused_kernel's phase 1
+  for (int item = wave; item < G + 2; item += 4) {
+    const int h = item == 0 ? H + kvh : (item == 1 ? H + KVH + kvh : kvh * Gt + (item - 2));
+    const bool act = lane < D / 2;
+    const int p = act ? lane : 0;
+    const uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+    const float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
+    bf16_t o0 = (bf16_t)(raw & 0xffff), o1 = (bf16_t)(raw >> 16);
+    if (item != 1) {
+      const bf16_t* nw = (item == 0) ? a.knw : a.qnw;
+      float y0 = x0, y1 = x1;
+      if (nw) {
+        const float ss = wave_sum(x0 * x0 + x1 * x1);
+        const float rstd = rsqrtf(ss / (float)D + a.eps);
+        y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(nw[2 * p])));
+        y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(nw[2 * p + 1])));
+      }
+      const uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+      const float cc = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
+      o0 = f2bf(__fsub_rn(__fmul_rn(y0, cc), __fmul_rn(y1, sn)));
+      o1 = f2bf(__fadd_rn(__fmul_rn(y1, cc), __fmul_rn(y0, sn)));
+    }
+    if (act) {
+      if (item >= 2) {
+        s_q[item - 2][2 * p] = bf2f(o0);
+        s_q[item - 2][2 * p + 1] = bf2f(o1);
+      } else {
+        if (!(a.slot_done && a.slot_done[slot])) {   // a finished slot no longer appends (its position may sit past its pages)
+          const int page = bt[pos / KV_PAGE];
+          bf16_t* pool = (item == 0) ? a.kpool : a.vpool;
+          *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kvh) * KV_PAGE + pos % KV_PAGE) * D + 2 * p) =
+              (uint32_t)o0 | ((uint32_t)o1 << 16);
+        }
+        float* dst = (item == 0) ? s_k : s_v;
+        dst[2 * p] = bf2f(o0);
+        dst[2 * p + 1] = bf2f(o1);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the new key's score per head
+  const float scale = 1.0f / sqrtf((float)D);
+  if (wave < G) {
+    float d = 0.f;
+    for (int i = lane; i < D; i += 64) d += s_q[wave][i] * s_k[i];
+    d = wave_sum(d);
+    if (lane == 0) s_s[wave] = d * scale;
+  }
+  __syncthreads();
+  // ---- merge: ATTN_Z partial states over the cached keys (in z order) and the new key
+  const float* part = a.part + (((int64_t)r * KVH + kvh) * ATTN_Z) * G * (D + 2);
+  for (int i = threadIdx.x; i < G * D; i += 256) {
+    const int gq = i / D, d = i % D;
+    float M = s_s[gq];
+#pragma unroll
+    for (int zz = 0; zz < ATTN_Z; ++zz) M = fmaxf(M, part[(zz * G + gq) * (D + 2)]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int zz = 0; zz < ATTN_Z; ++zz) {
+      const float* pz = part + (zz * G + gq) * (D + 2);
+      const float wgt = __expf(pz[0] - M);
+      L += pz[1] * wgt;
+      O += pz[2 + d] * wgt;
+    }
+    const float wn = __expf(s_s[gq] - M);
+    L += wn;
+    O += wn * s_v[d];
+    a.out[((int64_t)r * H + kvh * Gt + gq) * D + d] = f2bf(O / L);
+  }
+}
+
 // The query heads of a kv head are split over `split` work-groups (each re-reads the K/V rows, which are L2
 // hits): rows x KVH work-groups alone (64 at batch 8) leave three quarters of the CUs idle, and the per-head
 // score/softmax/PV arithmetic is the serial part of this latency-bound kernel.  FMI_ATTN_SPLIT overrides.
@@ -1685,6 +1990,30 @@ int launch_attn_decode_fused(const AttnArgs& a, hipStream_t s) {
     case 128: return launch_attn_decode_d<128>(a, s);
     default: return set_error(FMI_EINVAL, "attn: head_dim %d unsupported (32/64/128)", a.D);
   }
+}
+
+bool attn_decode_long_supported(int H, int KVH, int D) {
+  const int G = KVH > 0 && H % KVH == 0 ? H / KVH : 0;
+  return D == 128 && (G == 1 || G == 2 || G == 4);
+}
+
+int64_t attn_decode_long_part_floats(int rows, int H, int D) { return (int64_t)rows * H * ATTN_Z * (D + 2); }
+
+int launch_attn_decode_long(const AttnArgs& a, hipStream_t s) {
+  FMI_REQUIRE(attn_decode_long_supported(a.H, a.KVH, a.D) && a.part && a.long_thr > 0, "attn_decode_long: unsupported shape");
+  const int G = a.H / a.KVH;
+  dim3 g1(a.rows, a.KVH, ATTN_Z), g2(a.rows, a.KVH);
+#define FMI_LONG(G_)                                                                                  \
+  do {                                                                                                \
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<128, G_>), g1, dim3(256), 0, s, a);                   \
+    hipLaunchKernelGGL((attn_decode_merge_kernel<128, G_>), g2, dim3(256), 0, s, a);                  \
+  } while (0)
+  if (G == 1) FMI_LONG(1);
+  else if (G == 2) FMI_LONG(2);
+  else FMI_LONG(4);
+#undef FMI_LONG
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
 }
 
 // fast-AR attention (llama.py:948-976), S <= num_codebooks <= 16, everything rounded through bf16 like

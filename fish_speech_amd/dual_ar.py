@@ -533,6 +533,11 @@ class MiDualAR:
         """Prefill attention kernel: 1 = MFMA flash attention (default), 0 = VALU kernel (A/B parity runs)."""
         check(self.lib.fmi_dualar_set_attn_impl(self._h, int(impl)))
 
+    def set_attn_long_threshold(self, threshold: int):
+        """Decode attention: rows at or beyond this position use the MFMA kernel + merge, the others the fused VALU
+        kernel (default 1024; 0 = VALU for every row).  Call after setup_caches."""
+        check(self.lib.fmi_dualar_set_attn_long_threshold(self._h, int(threshold)))
+
     def set_ignore_eos(self, enable: bool):
         """Keep generating past <|im_end|> (fixed-length synthetic benchmarks)."""
         check(self.lib.fmi_dualar_set_ignore_eos(self._h, int(enable)))

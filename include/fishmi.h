@@ -175,6 +175,12 @@ int fmi_dualar_set_graph(fmi_dualar* h, int enable);
 /* Prefill attention implementation (F.scaled_dot_product_attention, llama.py:928-934): 1 = MFMA flash attention with
  * LDS-staged K/V tiles (default), 0 = the VALU kernel of round 1 (kept for A/B parity runs). */
 int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl);
+/* Decode attention (the per-frame step of llama.py:910-934 over the KV cache): rows whose position is >= threshold run
+ * on the MFMA kernel (all query heads of a kv head in one work-group, key ranges split over work-groups, partial
+ * softmax states merged), the others on the fused VALU kernel; which one depends only on the row's own position.
+ * Default 1024, the measured break-even at batch 8 (FMI_ATTN_THR overrides at setup_caches); 0 = VALU kernel for every
+ * row.  Call after setup_caches. */
+int fmi_dualar_set_attn_long_threshold(fmi_dualar* h, int threshold);
 /* Time of the last fmi_dualar_decode in ms measured with HIP events on `stream`, and the
  * number of kernel launches per frame. */
 int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_frame);

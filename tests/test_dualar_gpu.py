@@ -6,6 +6,8 @@ hidden) within 2 bf16 ulps (+1e-3 absolute) of the oracle -- the model computes 
 accumulation and only the fp32 summation ORDER differs from the CPU path."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -996,6 +998,87 @@ def test_mfma_flash_attention_ragged_batch_equals_single_prompts():
         l1, _, h1, _ = model.debug_taps(1)
         model.release(0)
         assert torch.equal(l1[0], logits[i]) and torch.equal(h1[0], hidden[i]), i
+
+
+@pytest.mark.parametrize("T", [520, 1100, 2047])
+def test_mfma_decode_attention_long_context_vs_oracle_and_valu_kernel(T):
+    """Decode attention at long contexts runs on MFMA (rows at or beyond a position threshold -- 1024 by default, 512 here: all query heads of a kv head in
+    one work-group, key ranges split over four work-groups, partial softmax states merged, the new token folded in by
+    the merge kernel).  After a T-token voice-clone shaped prompt (head_dim 128, 4 query heads per kv head: the S2
+    geometry) three teacher-forced decode positions: logits and hidden state against the CPU oracle (relative L2
+    <= 2 %) and against the fused VALU kernel on the same cache (<= 1 %), which also proves that the K/V rows the
+    merge kernel appends are the ones the VALU kernel would have appended (the later positions read them)."""
+    cfg = _long_cfg("mid", 2304)
+    state = O.make_synthetic_state(cfg, seed=6, head_gain=8.0)
+    model = _make_model(cfg, state, max_batch=1)
+    orc = O.DualAROracle(cfg, state)
+    orc.setup_caches(1, cfg.max_seq_len)
+    p = O.make_prompt(cfg, T, seed=T + 1, n_semantic=T // 2)
+    ncb1 = cfg.num_codebooks + 1
+    g = torch.Generator().manual_seed(T)
+    frames = torch.zeros(3, ncb1, dtype=torch.int64)
+    frames[:, 1:] = torch.randint(0, cfg.codebook_size, (3, cfg.num_codebooks), generator=g)
+    frames[:, 0] = frames[:, 1] + cfg.semantic_begin_id
+    ids = model._table(1, torch.int32).view(-1).long().cpu()
+    orc.forward_generate(p.view(1, ncb1, -1), torch.arange(T), math_backend=True)
+    want = [orc.forward_generate(frames[i].view(1, ncb1, 1), torch.tensor([T + i]), math_backend=True) for i in range(3)]
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    out = {}
+    for thr in (512, 0):
+        model.set_attn_long_threshold(thr)
+        model.forward_generate(p.view(1, ncb1, -1).to(DEV), torch.arange(T, device=DEV))
+        res = []
+        for i in range(3):
+            r = model.forward_generate(frames[i].view(1, ncb1, 1).to(DEV), torch.tensor([T + i], device=DEV))
+            res.append((r.logits[0, 0].float().cpu()[ids], r.hidden_states.float().cpu().view(-1)))
+        out[thr] = res
+    model.set_attn_long_threshold(1024)
+    for i in range(3):
+        wl, wh = want[i][0][0, 0].float()[ids], want[i][1].float().view(-1)
+        e = dict(mfma_vs_oracle=(rel(out[512][i][0], wl), rel(out[512][i][1], wh)),
+                 valu_vs_oracle=(rel(out[0][i][0], wl), rel(out[0][i][1], wh)),
+                 mfma_vs_valu=(rel(out[512][i][0], out[0][i][0]), rel(out[512][i][1], out[0][i][1])))
+        print("decode position", T + i, e)
+        assert max(e["mfma_vs_oracle"]) <= 2e-2, e
+        assert max(e["mfma_vs_valu"]) <= 1e-2, e
+        assert max(e["mfma_vs_oracle"]) <= 1.5 * max(e["valu_vs_oracle"]) + 4e-3, e
+
+
+def test_decode_attention_regimes_are_batch_invariant_and_graph_equals_eager():
+    """Which decode-attention kernel serves a row depends only on that row's position (threshold 512), so an utterance
+    keeps its batch-1 result whatever its batch-mates' contexts are: a ragged batch with prompts of 40, 700, 505 and
+    1300 tokens (short, long, one CROSSING the threshold during the run, long) -- the frame graph then launches both
+    kernels -- equals the four batch-1 runs bit for bit, through the hipGraph and eagerly; and the well-conditioned
+    fixture's greedy tokens do not change when every row is forced through the MFMA path."""
+    from fish_speech_amd.dual_ar import generate, generate_batch
+
+    cfg = _long_cfg("mid", 2304)
+    state = O.make_peaky_state(cfg, seed=93, emb_gain=2.5, slow_gain=3.0, fast_gain=2.5)
+    model = _make_model(cfg, state, max_batch=4)
+    model.set_attn_long_threshold(512)
+    lens = [40, 700, 505, 1300]
+    prompts = [O.make_prompt(cfg, T, seed=60 + i, n_semantic=T // 3) for i, T in enumerate(lens)]
+    kw = dict(max_new_tokens=14, temperature=0.7, top_p=0.7, top_k=30, stop_on_im_end=False)
+    seeds = [31, 32, 33, 34]
+    model.set_graph(True)
+    batch = generate_batch(model=model, prompts=prompts, seeds=seeds, **kw)
+    model.set_graph(False)
+    eager = generate_batch(model=model, prompts=prompts, seeds=seeds, **kw)
+    model.set_graph(True)
+    for i, p in enumerate(prompts):
+        assert torch.equal(batch[i], eager[i]), f"graph != eager for utterance {i}"
+        single = generate_batch(model=model, prompts=[p], seeds=[seeds[i]], **kw)[0]
+        assert torch.equal(single, batch[i]), f"utterance {i} (prompt {lens[i]}) differs from its batch-1 run"
+    # the decisions of a well-conditioned model do not depend on the attention kernel (threshold 1: MFMA for every row)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dualar_mid_peaky.npz"))
+    prompt = torch.from_numpy(z["prompt"])
+    gk = dict(prompt=prompt, max_new_tokens=int(z["max_new"]), temperature=0.7, top_p=0.7, top_k=1, seed=int(z["uniform_seed"]))
+    model.set_attn_long_threshold(0)
+    valu = generate(model=model, **gk)
+    model.set_attn_long_threshold(32)
+    mfma = generate(model=model, **gk)
+    model.set_attn_long_threshold(1024)
+    assert torch.equal(valu, mfma) and np.array_equal(valu.numpy(), z["tokens"])
 
 
 def test_prefix_reuse_is_bit_identical_for_every_length_class():

@@ -533,3 +533,33 @@ def test_engine_streaming_segments_equal_final_equal_offline():
     bad = list(engine.inference(TTSRequest(text=one, max_new_tokens=21, top_p=0.8, prompt_texts=["x"],
                                            prompt_tokens=[torch.zeros(3, 4, dtype=torch.long)])))
     assert bad[-1].code == "error" and isinstance(bad[-1].error, Exception)
+    # the engine re-prefills only what a text chunk adds: chunk 2's prompt repeats chunk 1's conversation (prefix-KV reuse)
+    model.prefilled_rows = model.reused_rows = 0
+    again = list(engine.inference(TTSRequest(streaming=False, **base)))
+    assert np.array_equal(again[0].audio[1], final) and model.reused_rows > 0
+
+    # concurrent requests from request threads (tools/api_server.py:115-122) are served one after the other
+    # under the model's lock -- every thread gets exactly its sequential result
+    import threading
+
+    reqs = [TTSRequest(text=text, max_new_tokens=21, chunk_length=30, seed=70 + i, first_chunk_frames=3, chunk_frames=5,
+                       streaming=bool(i % 2)) for i in range(4)]
+    want_audio = [[r for r in engine.inference(q)][-1].audio[1] for q in reqs]
+    got, errs = [None] * 4, []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            got[i] = [r for r in engine.inference(reqs[i])][-1].audio[1]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(got[i], want_audio[i]), i
+

@@ -44,20 +44,21 @@ fi
 
 # decode attention at long contexts: one kernel-trace run per context length
 if want attn; then
-{ echo "# attn_decode_fused_kernel (VALU, K/V rows streamed from the paged cache) at B = 8, S2-Pro shape: tools/attn_decode_probe.py T under rocprofv3 --kernel-trace --stats";
+{ echo "# decode attention at B = 8, S2-Pro shape over the context length: attn_decode_fused_kernel (VALU, rows below the threshold position) / attn_decode_mfma_kernel + attn_decode_merge_kernel (rows at or beyond it); tools/attn_decode_probe.py T under rocprofv3 --kernel-trace --stats";
   echo "# libfishmi.so sha1 $SHA, tree $HEAD; bytes per launch = 32768 x S; 'GB/s' = bytes / avg duration"; } > "$OUT/${TAG}_attn_decode.txt"
 for T in 300 1024 2048; do
-  ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$W/attn$T" -o a -- python "$R/tools/attn_decode_probe.py" $T ) > "$OUT/attn${T}_run.log" 2>&1
+  # (FMI_ATTN_THR=512 so that the MFMA pair is also measured at 1 k keys, below the shipped threshold of 1024)
+  ( cd /tmp && FMI_ATTN_THR=${ATTN_THR:-512} rocprofv3 --kernel-trace --stats -d "$W/attn$T" -o a -- python "$R/tools/attn_decode_probe.py" $T ) > "$OUT/attn${T}_run.log" 2>&1
   db=$(find "$W/attn$T" -name '*_results.db' | head -1)
   grep -h "^T=" "$OUT/attn${T}_run.log" >> "$OUT/${TAG}_attn_decode.txt"
   python - "$db" $T >> "$OUT/${TAG}_attn_decode.txt" <<'PY'
 import sqlite3, sys
 db, T = sys.argv[1], int(sys.argv[2])
 cur = sqlite3.connect(db).cursor()
-rows = list(cur.execute("select name, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where name like '%attn_decode_fused%' or name like '%linear_skinny%' group by name order by 3*count(*) desc limit 6"))
+rows = list(cur.execute("select name, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where name like '%attn_decode%' group by name order by name"))
 for name, n, avg, mn in rows:
     extra = ""
-    if "attn_decode" in name:
+    if "attn_decode_fused" in name or "attn_decode_mfma" in name:
         b = 32768 * (T + 10)
         extra = f"   <- {b / 1e6:.1f} MB per launch = {b / avg / 1e3:.0f} GB/s"
     print(f"  {avg:8.2f} us avg ({mn:.2f} min) x{n:5d}  {name[:90]}{extra}")
