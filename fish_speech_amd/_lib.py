@@ -113,6 +113,10 @@ def load() -> C.CDLL:
         raise FishmiError(
             f"{LIB_PATH} not found: build it with `python -m fish_speech_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch ships its own libamdhip64; the process must hold ONE HIP runtime, and the tensors / streams handed to the
+    # library are torch's, so torch's copy has to be the one that is resident when libfishmi.so resolves its
+    # dependency (loading the library first pulled in /opt/rocm's runtime and every hipStreamCreate then failed)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
