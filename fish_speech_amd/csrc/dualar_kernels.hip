@@ -915,9 +915,13 @@ __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
 // issues a DMA piece (60-185 cycles each, MI355X_MICROARCH.md) is the wave whose MFMAs then starve.  The cyclic
 // wave -> SIMD placement puts one compute and one loader wave of a work-group on every SIMD.  Operand reads of the
 // second k-tile are issued before the first k-tile's MFMAs.
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void linear_tiled_ws_kernel(LinearArgs a) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][A 16 pieces | B 16 pieces] x 1 KiB
+// WNT = 16-row weight tiles per compute wave: 4 (128 x 128 output tile, shipped) or 2 (128 rows x 64 columns: twice
+// the work-groups for the GEMMs whose 128-wide tiling leaves the chip half empty at M = 1600 -- wo / w2 260
+// work-groups, wqkv 624; 24 KiB per stage, three work-groups per CU; measured slower, see launch_linear_tiled).
+template <int EPI, int WNT>
+__global__ __launch_bounds__(512, WNT == 4 ? 4 : 6) void linear_tiled_ws_kernel(LinearArgs a) {
+  constexpr int NTW = 2 * WNT, AP = NTW * 2, NP = AP + 16, STAGE = NP * 1024;   // n-tiles, weight pieces, pieces, bytes
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][A AP pieces | B 16 pieces] x 1 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave8 >= 4;
@@ -925,21 +929,21 @@ __global__ __launch_bounds__(512, 4) void linear_tiled_ws_kernel(LinearArgs a) {
   const int wn = wave & 1, wm = wave >> 1;
   const int KT = a.K >> 5, KS = (KT + 1) >> 1;  // k-steps of two k-tiles (the last may hold one)
   const int NT = a.N >> 4;
-  const int n_blk0 = blockIdx.x * 8, m_blk0 = blockIdx.y * 128;
+  const int n_blk0 = blockIdx.x * NTW, m_blk0 = blockIdx.y * 128;
   const int mi = lane & 15, g = lane >> 4;
   const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
 
   auto stage = [&](int ks, int buf) {
-    char* base = smem + buf * 32768;
-    for (int p = wave; p < 32; p += 4) {       // pieces 0-15: weights, 16-31: activations; piece = tile*2 + kk
+    char* base = smem + buf * STAGE;
+    for (int p = wave; p < NP; p += 4) {       // pieces 0..AP-1: weights, then 16 of activations; piece = tile*2 + kk
       const int kk = p & 1, j = 2 * ks + kk;
       if (j >= KT) continue;                   // unpaired last k-tile: second half of the step is empty
-      if (p < 16) {
+      if (p < AP) {
         const int nt = min(n_blk0 + (p >> 1), NT - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + ((int64_t)nt * KT + j) * 64 + lane),
                                          (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
       } else {
-        const int mt = (p - 16) >> 1;
+        const int mt = (p - AP) >> 1;
         const int m = min(m_blk0 + mt * 16 + mi, a.M - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + (int64_t)m * a.ldx + packed_k0(j, g, KT)),
                                          (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
@@ -957,61 +961,71 @@ __global__ __launch_bounds__(512, 4) void linear_tiled_ws_kernel(LinearArgs a) {
     return;
   }
 
-  f32x4 acc[4][4];
+  f32x4 acc[WNT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WNT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u;
 
   for (int ks = 0; ks < KS; ++ks) {            // K / 32 is even here (launch_linear_tiled): every step holds two k-tiles
     __syncthreads();
-    const unsigned b0 = lds0 + (unsigned)((ks & 1) * 32768);
-    u32x4 wv0[4], xv[4], wv1[4];
+    const unsigned b0 = lds0 + (unsigned)((ks & 1) * STAGE);
+    u32x4 wv0[WNT], xv[4], wv1[WNT];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      wv0[t] = lds_read_b128(b0 + (unsigned)(((wn * 4 + t) * 2) * 1024));
-      xv[t] = lds_read_b128(b0 + (unsigned)((16 + (wm * 4 + t) * 2) * 1024));
+      if (t < WNT) wv0[t] = lds_read_b128(b0 + (unsigned)(((wn * WNT + t) * 2) * 1024));
+      xv[t] = lds_read_b128(b0 + (unsigned)((AP + (wm * 4 + t) * 2) * 1024));
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wv1[t] = lds_read_b128(b0 + (unsigned)(((wn * 4 + t) * 2 + 1) * 1024));
+    for (int t = 0; t < WNT; ++t) wv1[t] = lds_read_b128(b0 + (unsigned)(((wn * WNT + t) * 2 + 1) * 1024));
     // (the waits name the registers they make valid: MFMA builtins are not memory operations, so nothing else keeps
     // the compiler from scheduling a product above the wait for its operand)
-    asm volatile("s_waitcnt lgkmcnt(4)"   // the first k-tile's eight reads are back
-                 : "+v"(wv0[0]), "+v"(wv0[1]), "+v"(wv0[2]), "+v"(wv0[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
-                 :: "memory");
-    // activation-tile-major order: once the four products of activation tile tm are issued its register is free
+    if constexpr (WNT == 4)
+      asm volatile("s_waitcnt lgkmcnt(4)"   // the first k-tile's reads are back
+                   : "+v"(wv0[0]), "+v"(wv0[1]), "+v"(wv0[2]), "+v"(wv0[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
+                   :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(2)"
+                   : "+v"(wv0[0]), "+v"(wv0[1]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
+                   :: "memory");
+    // activation-tile-major order: once the products of activation tile tm are issued its register is free
     // for the SECOND k-tile's fragment, which then arrives under the remaining products (128-register budget:
     // two work-groups = four waves per SIMD)
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
+      for (int tn = 0; tn < WNT; ++tn)
         acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv0[tn]),
                                                               *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
-      xv[tm] = lds_read_b128(b0 + (unsigned)((16 + (wm * 4 + tm) * 2 + 1) * 1024));
+      xv[tm] = lds_read_b128(b0 + (unsigned)((AP + (wm * 4 + tm) * 2 + 1) * 1024));
       __builtin_amdgcn_sched_barrier(0);   // keep each reload right behind the products that freed its register
     }
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(wv1[0]), "+v"(wv1[1]), "+v"(wv1[2]), "+v"(wv1[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
-                 :: "memory");
+    if constexpr (WNT == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(wv1[0]), "+v"(wv1[1]), "+v"(wv1[2]), "+v"(wv1[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
+                   :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(wv1[0]), "+v"(wv1[1]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3])
+                   :: "memory");
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
+      for (int tn = 0; tn < WNT; ++tn)
         acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv1[tn]),
                                                               *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
   }
 
   // epilogue identical to the other variants: lane holds D[n = tile*16 + g*4 + j][m = tile*16 + mi]
-  const int n_tile0 = n_blk0 + wn * 4, m0 = m_blk0 + wm * 64;
+  const int n_tile0 = n_blk0 + wn * WNT, m0 = m_blk0 + wm * 64;
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
     const int m = m0 + tm * 16 + mi;
     if (m >= a.M) continue;
     if (EPI == EPI_SILU) {
 #pragma unroll
-      for (int tp = 0; tp < 2; ++tp) {
+      for (int tp = 0; tp < WNT / 2; ++tp) {
         const int nt_gate = n_tile0 + tp * 2;
         if (nt_gate >= NT) continue;
         const int n = (nt_gate >> 1) * 16 + g * 4;
@@ -1026,7 +1040,7 @@ __global__ __launch_bounds__(512, 4) void linear_tiled_ws_kernel(LinearArgs a) {
       }
     } else {
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
+      for (int tn = 0; tn < WNT; ++tn) {
         if (n_tile0 + tn >= NT) continue;
         const int n = (n_tile0 + tn) * 16 + g * 4;
         bf16_t o[4];
@@ -1056,13 +1070,31 @@ int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, i
   if (mode == 'w' && ((a.K >> 5) & 1)) mode = 'l';   // the wave-specialised loop takes k-tiles in pairs
   constexpr int smem = 2 * 32768;
   if (mode == 'w') {
-    static const hipError_t at0 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    static const hipError_t at1 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    static const hipError_t at2 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    // 64-column tiles (FMI_GEMM_NT=4, A/B only): twice the work-groups for wo / w2 / wqkv at 8 x 200 rows, but a third
+    // less reuse per staged byte on a tile that already sits on the address-path ridge -- measured 28.5 against 26.0 ms
+    // for the prefill of 8 x 200 tokens (101.3 / 101.4 at 8 x 1024, 208.6 / 207.9 at 8 x 2048): not used
+    static const int env_nt = []() { const char* e = getenv("FMI_GEMM_NT"); return e ? atoi(e) : 0; }();
+    const bool narrow = env_nt == 4 && a.N % 64 == 0;
+    if (narrow) {
+      constexpr int smem4 = 2 * 24 * 1024;
+      static const hipError_t b0 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_STORE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem4);
+      static const hipError_t b1 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_RESIDUAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem4);
+      static const hipError_t b2 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_SILU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem4);
+      FMI_CHECK_HIP(b0); FMI_CHECK_HIP(b1); FMI_CHECK_HIP(b2);
+      dim3 grid4(cdiv(a.N / 16, 4), grid.y);
+      if (a.epi == EPI_STORE) hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_STORE, 2>), grid4, dim3(512), smem4, s, a);
+      else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_RESIDUAL, 2>), grid4, dim3(512), smem4, s, a);
+      else hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_SILU, 2>), grid4, dim3(512), smem4, s, a);
+      FMI_CHECK_HIP(hipGetLastError());
+      return FMI_OK;
+    }
+    static const hipError_t at0 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_STORE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t at1 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_RESIDUAL, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t at2 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_SILU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     FMI_CHECK_HIP(at0); FMI_CHECK_HIP(at1); FMI_CHECK_HIP(at2);
-    if (a.epi == EPI_STORE) hipLaunchKernelGGL(linear_tiled_ws_kernel<EPI_STORE>, grid, dim3(512), smem, s, a);
-    else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL(linear_tiled_ws_kernel<EPI_RESIDUAL>, grid, dim3(512), smem, s, a);
-    else hipLaunchKernelGGL(linear_tiled_ws_kernel<EPI_SILU>, grid, dim3(512), smem, s, a);
+    if (a.epi == EPI_STORE) hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_STORE, 4>), grid, dim3(512), smem, s, a);
+    else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_RESIDUAL, 4>), grid, dim3(512), smem, s, a);
+    else hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_SILU, 4>), grid, dim3(512), smem, s, a);
     FMI_CHECK_HIP(hipGetLastError());
     return FMI_OK;
   }
