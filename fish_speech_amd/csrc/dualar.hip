@@ -1011,7 +1011,7 @@ int fmi_dualar_decode(fmi_dualar* h, int n, const int32_t* slot_ids, int n_frame
   h->attn_mask = mask;
   hipGraphExec_t exec = nullptr;
   if (h->use_graph && !h->trace) {
-    const int key = n | (mask << 8);
+    const int key = n * 4 + mask;
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipGraph_t g = nullptr;
