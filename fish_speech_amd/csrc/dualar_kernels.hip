@@ -918,33 +918,66 @@ __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
 // WNT = 16-row weight tiles per compute wave: 4 (128 x 128 output tile, shipped) or 2 (128 rows x 64 columns: twice
 // the work-groups for the GEMMs whose 128-wide tiling leaves the chip half empty at M = 1600 -- wo / w2 260
 // work-groups, wqkv 624; 24 KiB per stage, three work-groups per CU; measured slower, see launch_linear_tiled).
-template <int EPI, int WNT>
-__global__ __launch_bounds__(512, WNT == 4 ? 4 : 6) void linear_tiled_ws_kernel(LinearArgs a) {
-  constexpr int NTW = 2 * WNT, AP = NTW * 2, NP = AP + 16, STAGE = NP * 1024;   // n-tiles, weight pieces, pieces, bytes
-  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][A AP pieces | B 16 pieces] x 1 KiB
+// resource ablations for tools/gemm_bench.hip (results are garbage): 2 = no products, 3 = no operand reads
+#if defined(FMI_WS_ABLATE) && (FMI_WS_ABLATE == 2 || (FMI_WS_ABLATE >= 5 && FMI_WS_ABLATE != 9))
+#define FMI_WS_MFMA(w, x, c) ({ asm volatile("" :: "v"(w), "v"(x)); (c); })
+#else
+#define FMI_WS_MFMA(w, x, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&(w)), *reinterpret_cast<bf16x8*>(&(x)), (c), 0, 0, 0)
+#endif
+#if defined(FMI_WS_ABLATE) && (FMI_WS_ABLATE == 3 || (FMI_WS_ABLATE >= 6 && FMI_WS_ABLATE != 9))
+#define FMI_WS_READ(addr) ((u32x4){(addr), 1u, 2u, 3u})
+#else
+#define FMI_WS_READ(addr) lds_read_b128(addr)
+#endif
+// CW = compute waves (CW/2 along N x 2 along M, each 16*WNT columns x 64 rows), NS = LDS stages.  CW = 8, NS = 3 is the
+// 128-row x 256-column tile: 48 KiB per k-step for twice the products of the 128 x 128 tile's 32 KiB -- the operand
+// path of a CU delivers ~20-23 B/clk whatever the L2 hit rate and whether the bytes go by LDS-DMA or through
+// registers (tools/gemm_bench.hip ablations, profiles/r03_gemm_ablation.txt), so bytes per product are what counts.
+// One 12-wave work-group per CU (two compute waves + one loader wave per SIMD); the loaders run two k-steps ahead.
+template <int EPI, int WNT, int CW = 4, int NS = 2>
+__global__ __launch_bounds__((CW + 4) * 64, CW == 8 ? 3 : WNT == 4 ? 4 : 6) void linear_tiled_ws_kernel(LinearArgs a) {
+  constexpr int WN = CW / 2;
+  constexpr int NTW = WN * WNT, AP = NTW * 2, NP = AP + 16, STAGE = NP * 1024;   // n-tiles, weight pieces, pieces, bytes
+  constexpr int PW = NP / 4;                                                     // pieces per loader wave and k-step
+  static_assert(NP % 4 == 0 && (NS == 2 || NS == 3), "linear_tiled_ws_kernel: bad configuration");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NS stages][A AP pieces | B 16 pieces] x 1 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave8 >= 4;
-  const int wave = wave8 & 3;
-  const int wn = wave & 1, wm = wave >> 1;
+  const bool loader = wave8 >= CW;
+  const int wave = loader ? wave8 - CW : wave8;
+  const int wn = wave % WN, wm = wave / WN;
   const int KT = a.K >> 5, KS = (KT + 1) >> 1;  // k-steps of two k-tiles (the last may hold one)
   const int NT = a.N >> 4;
   const int n_blk0 = blockIdx.x * NTW, m_blk0 = blockIdx.y * 128;
   const int mi = lane & 15, g = lane >> 4;
   const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
+#if defined(FMI_WS_ABLATE) && (FMI_WS_ABLATE == 4 || FMI_WS_ABLATE == 5)   // every work-group stages tile (0, 0): all operand traffic hits in L2
+  const int n_src0 = 0, m_src0 = 0;
+#else
+  const int n_src0 = n_blk0, m_src0 = m_blk0;
+#endif
 
   auto stage = [&](int ks, int buf) {
     char* base = smem + buf * STAGE;
     for (int p = wave; p < NP; p += 4) {       // pieces 0..AP-1: weights, then 16 of activations; piece = tile*2 + kk
+#if defined(FMI_WS_ABLATE) && FMI_WS_ABLATE >= 9      // every step re-reads the work-group's FIRST k-step: L2-resident operands, no hot spot
+      const int kk = p & 1, j = kk + 0 * ks;
+#else
       const int kk = p & 1, j = 2 * ks + kk;
+#endif
       if (j >= KT) continue;                   // unpaired last k-tile: second half of the step is empty
+#if defined(FMI_WS_ABLATE) && FMI_WS_ABLATE == 7
+      if (p >= AP) continue;
+#elif defined(FMI_WS_ABLATE) && FMI_WS_ABLATE == 8
+      if (p < AP) continue;
+#endif
       if (p < AP) {
-        const int nt = min(n_blk0 + (p >> 1), NT - 1);
+        const int nt = min(n_src0 + (p >> 1), NT - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + ((int64_t)nt * KT + j) * 64 + lane),
                                          (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
       } else {
         const int mt = (p - AP) >> 1;
-        const int m = min(m_blk0 + mt * 16 + mi, a.M - 1);
+        const int m = min(m_src0 + mt * 16 + mi, a.M - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + (int64_t)m * a.ldx + packed_k0(j, g, KT)),
                                          (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
       }
@@ -952,11 +985,24 @@ __global__ __launch_bounds__(512, WNT == 4 ? 4 : 6) void linear_tiled_ws_kernel(
   };
 
   if (loader) {
-    stage(0, 0);
+    for (int i = 0; i < NS - 1 && i < KS; ++i) stage(i, i);
+    int nb = NS - 1;                           // buffer of the next step to issue
     for (int ks = 0; ks < KS; ++ks) {
-      __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this wave's pieces of step ks have landed
-      __syncthreads();                         // ... everyone's have; the compute waves are done with buffer (ks+1)&1
-      if (ks + 1 < KS) stage(ks + 1, (ks + 1) & 1);
+      // this wave's pieces of step ks have landed (with three stages the next step's PW pieces may stay in flight)
+      if (NS == 3 && ks + 1 < KS) {
+        if constexpr (PW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        static_assert(NS == 2 || PW == 12 || PW == 8, "vmcnt literal");
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0)
+      }
+      __syncthreads();                         // ... everyone's have; the compute waves are done with the buffer of step ks-1
+#if defined(FMI_WS_ABLATE) && FMI_WS_ABLATE == 1   // tools/gemm_bench.hip: no DMA in the steady state
+      if (ks + NS - 1 < NS) stage(ks + NS - 1, nb);
+#else
+      if (ks + NS - 1 < KS) stage(ks + NS - 1, nb);
+#endif
+      nb = nb + 1 == NS ? 0 : nb + 1;
     }
     return;
   }
@@ -968,17 +1014,19 @@ __global__ __launch_bounds__(512, WNT == 4 ? 4 : 6) void linear_tiled_ws_kernel(
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u;
 
+  int cb = 0;
   for (int ks = 0; ks < KS; ++ks) {            // K / 32 is even here (launch_linear_tiled): every step holds two k-tiles
     __syncthreads();
-    const unsigned b0 = lds0 + (unsigned)((ks & 1) * STAGE);
+    const unsigned b0 = lds0 + (unsigned)(cb * STAGE);
+    cb = cb + 1 == NS ? 0 : cb + 1;
     u32x4 wv0[WNT], xv[4], wv1[WNT];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (t < WNT) wv0[t] = lds_read_b128(b0 + (unsigned)(((wn * WNT + t) * 2) * 1024));
-      xv[t] = lds_read_b128(b0 + (unsigned)((AP + (wm * 4 + t) * 2) * 1024));
+      if (t < WNT) wv0[t] = FMI_WS_READ(b0 + (unsigned)(((wn * WNT + t) * 2) * 1024));
+      xv[t] = FMI_WS_READ(b0 + (unsigned)((AP + (wm * 4 + t) * 2) * 1024));
     }
 #pragma unroll
-    for (int t = 0; t < WNT; ++t) wv1[t] = lds_read_b128(b0 + (unsigned)(((wn * WNT + t) * 2 + 1) * 1024));
+    for (int t = 0; t < WNT; ++t) wv1[t] = FMI_WS_READ(b0 + (unsigned)(((wn * WNT + t) * 2 + 1) * 1024));
     // (the waits name the registers they make valid: MFMA builtins are not memory operations, so nothing else keeps
     // the compiler from scheduling a product above the wait for its operand)
     if constexpr (WNT == 4)
@@ -996,9 +1044,8 @@ __global__ __launch_bounds__(512, WNT == 4 ? 4 : 6) void linear_tiled_ws_kernel(
     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
       for (int tn = 0; tn < WNT; ++tn)
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv0[tn]),
-                                                              *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
-      xv[tm] = lds_read_b128(b0 + (unsigned)((AP + (wm * 4 + tm) * 2 + 1) * 1024));
+        acc[tn][tm] = FMI_WS_MFMA(wv0[tn], xv[tm], acc[tn][tm]);
+      xv[tm] = FMI_WS_READ(b0 + (unsigned)((AP + (wm * 4 + tm) * 2 + 1) * 1024));
       __builtin_amdgcn_sched_barrier(0);   // keep each reload right behind the products that freed its register
     }
     if constexpr (WNT == 4)
@@ -1013,8 +1060,7 @@ __global__ __launch_bounds__(512, WNT == 4 ? 4 : 6) void linear_tiled_ws_kernel(
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int tn = 0; tn < WNT; ++tn)
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv1[tn]),
-                                                              *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
+        acc[tn][tm] = FMI_WS_MFMA(wv1[tn], xv[tm], acc[tn][tm]);
   }
 
   // epilogue identical to the other variants: lane holds D[n = tile*16 + g*4 + j][m = tile*16 + mi]
@@ -1066,9 +1112,22 @@ int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, i
   dim3 grid(cdiv(a.N / 16, 8), cdiv(a.M, 128)), block(256);
   // A/B switch: FMI_GEMM = d (operands straight from L2), l (LDS-staged, 4 waves), w (LDS-staged, wave-specialised)
   static const char env_mode = []() { const char* e = getenv("FMI_GEMM"); return e ? e[0] : '\0'; }();
-  char mode = force_direct ? 'd' : variant == 1 ? 'l' : variant == 2 ? 'w' : env_mode ? env_mode : FMI_GEMM_DEFAULT;
-  if (mode == 'w' && ((a.K >> 5) & 1)) mode = 'l';   // the wave-specialised loop takes k-tiles in pairs
+  char mode = force_direct ? 'd' : variant == 1 ? 'l' : variant == 2 ? 'w' : variant == 3 ? 'x' : env_mode ? env_mode : FMI_GEMM_DEFAULT;
+  if ((mode == 'w' || mode == 'x') && ((a.K >> 5) & 1)) mode = 'l';   // the wave-specialised loop takes k-tiles in pairs
   constexpr int smem = 2 * 32768;
+  if (mode == 'x') {   // 128 x 256 tile, 8 compute + 4 loader waves, three 48 KiB stages
+    constexpr int smem_x = 3 * 48 * 1024;
+    static const hipError_t x0 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_STORE, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_x);
+    static const hipError_t x1 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_RESIDUAL, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_x);
+    static const hipError_t x2 = hipFuncSetAttribute((const void*)linear_tiled_ws_kernel<EPI_SILU, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_x);
+    FMI_CHECK_HIP(x0); FMI_CHECK_HIP(x1); FMI_CHECK_HIP(x2);
+    dim3 grid_x(cdiv(a.N / 16, 16), grid.y);
+    if (a.epi == EPI_STORE) hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_STORE, 4, 8, 3>), grid_x, dim3(768), smem_x, s, a);
+    else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_RESIDUAL, 4, 8, 3>), grid_x, dim3(768), smem_x, s, a);
+    else hipLaunchKernelGGL((linear_tiled_ws_kernel<EPI_SILU, 4, 8, 3>), grid_x, dim3(768), smem_x, s, a);
+    FMI_CHECK_HIP(hipGetLastError());
+    return FMI_OK;
+  }
   if (mode == 'w') {
     // 64-column tiles (FMI_GEMM_NT=4, A/B only): twice the work-groups for wo / w2 / wqkv at 8 x 200 rows, but a third
     // less reuse per staged byte on a tile that already sits on the address-path ridge -- measured 28.5 against 26.0 ms

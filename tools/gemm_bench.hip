@@ -1,0 +1,102 @@
+// gemm_bench.hip -- the prefill GEMM variants (launch_linear_tiled: 'l' 4-wave LDS-staged, 'w' wave-specialised, 'x' the
+// 8-compute-wave 128 x 256 tile) on the S2-Pro prefill shapes, M = 8 x 200 and 8 x 2048 rows (round 3).
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFMI_WS_ABLATE=n] tools/gemm_bench.hip fish_speech_amd/csrc/common.cpp -o tools/bin/gemm_bench
+// Usage:  gemm_bench [variants, default lw] [shape name] [M]
+//   FMI_WS_ABLATE (resource ablation of the 'w' kernel, results are garbage): 1 = the loader waves issue only the first
+//   two stages (no DMA in the steady state), 2 = no MFMA (operand reads only), 3 = no operand reads (MFMA on stale registers)
+// Every variant is checked bit for bit against 'l' (same products, same order) and timed over NBUF weight copies.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../fish_speech_amd/csrc/dualar_kernels.hip"
+
+using namespace fmi;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+struct Shape { const char* name; int N, K, epi; };
+
+static uint32_t rng_state = 12345;
+static inline uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state; }
+static inline bf16_t rnd_bf16(float scale) {
+  float f = ((int)(rnd() >> 8) - (1 << 23)) * (scale / (1 << 23));
+  uint32_t u; memcpy(&u, &f, 4);
+  return (bf16_t)(u >> 16);
+}
+
+int main(int argc, char** argv) {
+  const Shape shapes[] = {{"wqkv", 6144, 2560, EPI_STORE}, {"wo", 2560, 4096, EPI_RESIDUAL}, {"w1|w3", 19456, 2560, EPI_SILU}, {"w2", 2560, 9728, EPI_RESIDUAL}};
+  const int Ms[] = {1600, 16384};
+  const char* variants = argc > 1 ? argv[1] : "lw";
+  const char* only_shape = argc > 2 ? argv[2] : "";      // e.g. "w2"; "" = all
+  const int only_m = argc > 3 ? atoi(argv[3]) : 0;       // 0 = both row counts
+  const int NBUF = 3;
+  for (int M : Ms) {
+    if (only_m && M != only_m) continue;
+    double total[8] = {0};
+    for (const Shape& sh : shapes) {
+      if (only_shape[0] && strcmp(only_shape, sh.name)) continue;
+      const int n_out = sh.epi == EPI_SILU ? sh.N / 2 : sh.N;
+      std::vector<bf16_t> hw((size_t)sh.N * sh.K), hx((size_t)M * sh.K), hr((size_t)M * n_out);
+      for (auto& v : hw) v = rnd_bf16(0.05f);
+      for (auto& v : hx) v = rnd_bf16(1.0f);
+      for (auto& v : hr) v = rnd_bf16(1.0f);
+      bf16_t *raw, *x, *res, *out, *ref; std::vector<bf16_t*> w(NBUF);
+      CK(hipMalloc(&raw, hw.size() * 2)); CK(hipMalloc(&x, hx.size() * 2)); CK(hipMalloc(&res, hr.size() * 2));
+      CK(hipMalloc(&out, hr.size() * 2)); CK(hipMalloc(&ref, hr.size() * 2));
+      CK(hipMemcpy(raw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(res, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
+      for (auto& p : w) {
+        CK(hipMalloc(&p, hw.size() * 2));
+        int rc;
+        if (sh.epi == EPI_SILU) {   // gate rows and up rows interleaved per 16-row tile, like the w1 / w3 loads
+          rc = launch_pack_weight(raw, p, sh.N / 2, sh.K, 1, 0);
+          if (!rc) rc = launch_pack_weight(raw + (size_t)(sh.N / 2) * sh.K, p, sh.N / 2, sh.K, 2, 0);
+        } else {
+          rc = launch_pack_weight(raw, p, sh.N, sh.K, 0, 0);
+        }
+        if (rc) { printf("pack failed\n"); return 1; }
+      }
+      CK(hipDeviceSynchronize());
+      LinearArgs a{};
+      a.x = x; a.ldx = sh.K; a.res = res; a.ldr = n_out; a.out = ref; a.ldo = n_out; a.M = M; a.N = sh.N; a.K = sh.K; a.epi = sh.epi; a.wp = w[0];
+      if (launch_linear_tiled(a, 0, false, 1)) { printf("launch failed: %s\n", g_last_error.c_str()); return 1; }
+      CK(hipDeviceSynchronize());
+      const double flop = 2.0 * M * sh.N * sh.K;
+      printf("M=%5d %-6s N=%5d K=%5d :", M, sh.name, sh.N, sh.K);
+      int vi = 0;
+      for (const char* v = variants; *v; ++v, ++vi) {
+        const int variant = *v == 'l' ? 1 : *v == 'w' ? 2 : 3;
+        a.out = out; a.wp = w[0];
+        CK(hipMemset(out, 0xff, hr.size() * 2));
+        if (launch_linear_tiled(a, 0, false, variant)) { printf("launch failed: %s\n", g_last_error.c_str()); return 1; }
+        CK(hipDeviceSynchronize());
+        std::vector<bf16_t> got(hr.size()), want(hr.size());
+        CK(hipMemcpy(got.data(), out, got.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(want.data(), ref, want.size() * 2, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < got.size(); ++i) bad += got[i] != want[i];
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int iters = M > 4000 ? 10 : 40;
+        for (int i = 0; i < 3; ++i) { a.wp = w[i % NBUF]; launch_linear_tiled(a, 0, false, variant); }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) { a.wp = w[i % NBUF]; launch_linear_tiled(a, 0, false, variant); }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters;
+        total[vi] += us;
+        printf("  %c %8.1f us %6.0f TF/s%s", *v, us, flop / us * 1e-6, bad ? " DIFF" : "");
+      }
+      printf("\n");
+      hipFree(raw); hipFree(x); hipFree(res); hipFree(out); hipFree(ref); for (auto p : w) hipFree(p);
+    }
+    printf("M=%5d layer total:", M);
+    int vi = 0;
+    for (const char* v = variants; *v; ++v, ++vi) printf("  %c %8.1f us (%.3f of 2.5 PF)", *v, total[vi], 2.0 * M * 101007360.0 / total[vi] * 1e-6 / 2.5e6);
+    printf("\n");
+  }
+  return 0;
+}
