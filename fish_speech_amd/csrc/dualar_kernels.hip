@@ -918,17 +918,6 @@ __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
 // WNT = 16-row weight tiles per compute wave: 4 (128 x 128 output tile, shipped) or 2 (128 rows x 64 columns: twice
 // the work-groups for the GEMMs whose 128-wide tiling leaves the chip half empty at M = 1600 -- wo / w2 260
 // work-groups, wqkv 624; 24 KiB per stage, three work-groups per CU; measured slower, see launch_linear_tiled).
-// resource ablations for tools/gemm_bench.hip (results are garbage): 2 = no products, 3 = no operand reads
-#if defined(FMI_WS_ABLATE) && (FMI_WS_ABLATE == 2 || (FMI_WS_ABLATE >= 5 && FMI_WS_ABLATE != 9))
-#define FMI_WS_MFMA(w, x, c) ({ asm volatile("" :: "v"(w), "v"(x)); (c); })
-#else
-#define FMI_WS_MFMA(w, x, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&(w)), *reinterpret_cast<bf16x8*>(&(x)), (c), 0, 0, 0)
-#endif
-#if defined(FMI_WS_ABLATE) && (FMI_WS_ABLATE == 3 || (FMI_WS_ABLATE >= 6 && FMI_WS_ABLATE != 9))
-#define FMI_WS_READ(addr) ((u32x4){(addr), 1u, 2u, 3u})
-#else
-#define FMI_WS_READ(addr) lds_read_b128(addr)
-#endif
 // CW = compute waves (CW/2 along N x 2 along M, each 16*WNT columns x 64 rows), NS = LDS stages.  CW = 8, NS = 3 is the
 // 128-row x 256-column tile: 48 KiB per k-step for twice the products of the 128 x 128 tile's 32 KiB -- the operand
 // path of a CU delivers ~20-23 B/clk whatever the L2 hit rate and whether the bytes go by LDS-DMA or through
@@ -951,40 +940,33 @@ __global__ __launch_bounds__((CW + 4) * 64, CW == 8 ? 3 : WNT == 4 ? 4 : 6) void
   const int n_blk0 = blockIdx.x * NTW, m_blk0 = blockIdx.y * 128;
   const int mi = lane & 15, g = lane >> 4;
   const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
-#if defined(FMI_WS_ABLATE) && (FMI_WS_ABLATE == 4 || FMI_WS_ABLATE == 5)   // every work-group stages tile (0, 0): all operand traffic hits in L2
-  const int n_src0 = 0, m_src0 = 0;
-#else
-  const int n_src0 = n_blk0, m_src0 = m_blk0;
-#endif
-
-  auto stage = [&](int ks, int buf) {
-    char* base = smem + buf * STAGE;
-    for (int p = wave; p < NP; p += 4) {       // pieces 0..AP-1: weights, then 16 of activations; piece = tile*2 + kk
-#if defined(FMI_WS_ABLATE) && FMI_WS_ABLATE >= 9      // every step re-reads the work-group's FIRST k-step: L2-resident operands, no hot spot
-      const int kk = p & 1, j = kk + 0 * ks;
-#else
-      const int kk = p & 1, j = 2 * ks + kk;
-#endif
-      if (j >= KT) continue;                   // unpaired last k-tile: second half of the step is empty
-#if defined(FMI_WS_ABLATE) && FMI_WS_ABLATE == 7
-      if (p >= AP) continue;
-#elif defined(FMI_WS_ABLATE) && FMI_WS_ABLATE == 8
-      if (p < AP) continue;
-#endif
-      if (p < AP) {
-        const int nt = min(n_src0 + (p >> 1), NT - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + ((int64_t)nt * KT + j) * 64 + lane),
-                                         (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+  if (loader) {
+    // One loader wave owns pieces p = wave + 4 i (i < PW) of every stage: k-tile kk = wave & 1 of the step, weight
+    // tiles 2 i + (wave >> 1) for i < AP / 4, then activation row tiles.  All per-lane source addresses are formed
+    // ONCE; a k-step adds a constant (two packed weight tiles = 2 KiB; 64 activation columns = 128 B, packed_k0 is
+    // linear in the step for paired k-tiles).  The loop this replaced recomputed tile / row / packed_k0 / min() per
+    // piece behind a non-unrolled branchy loop: ~30 instructions per 1 KiB piece, and the loaders -- not the L2, not
+    // the LDS-DMA path -- bounded the kernel (profiles/r03_gemm_ablation.txt: 1 KiB per ~300 cycles per loader wave
+    // whatever the hit rate or the number of pieces in flight).
+    const int kk = wave & 1, half = wave >> 1;
+    const char* src[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      if (i < AP / 4) {
+        const int nt = min(n_blk0 + 2 * i + half, NT - 1);
+        src[i] = reinterpret_cast<const char*>(wp + ((int64_t)nt * KT + kk) * 64 + lane);
       } else {
-        const int mt = (p - AP) >> 1;
-        const int m = min(m_src0 + mt * 16 + mi, a.M - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + (int64_t)m * a.ldx + packed_k0(j, g, KT)),
-                                         (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+        const int m = min(m_blk0 + (2 * (i - AP / 4) + half) * 16 + mi, a.M - 1);
+        src[i] = reinterpret_cast<const char*>(a.x + (int64_t)m * a.ldx + (g >> 1) * 32 + (((g & 1) << 1) + kk) * 8);
       }
     }
-  };
-
-  if (loader) {
+    auto stage = [&](int ks, int buf) {
+      char* base = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < PW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)ks * (i < AP / 4 ? 2048 : 128)),
+                                         (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+    };
     for (int i = 0; i < NS - 1 && i < KS; ++i) stage(i, i);
     int nb = NS - 1;                           // buffer of the next step to issue
     for (int ks = 0; ks < KS; ++ks) {
@@ -997,11 +979,7 @@ __global__ __launch_bounds__((CW + 4) * 64, CW == 8 ? 3 : WNT == 4 ? 4 : 6) void
         __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0)
       }
       __syncthreads();                         // ... everyone's have; the compute waves are done with the buffer of step ks-1
-#if defined(FMI_WS_ABLATE) && FMI_WS_ABLATE == 1   // tools/gemm_bench.hip: no DMA in the steady state
-      if (ks + NS - 1 < NS) stage(ks + NS - 1, nb);
-#else
       if (ks + NS - 1 < KS) stage(ks + NS - 1, nb);
-#endif
       nb = nb + 1 == NS ? 0 : nb + 1;
     }
     return;
@@ -1022,11 +1000,11 @@ __global__ __launch_bounds__((CW + 4) * 64, CW == 8 ? 3 : WNT == 4 ? 4 : 6) void
     u32x4 wv0[WNT], xv[4], wv1[WNT];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (t < WNT) wv0[t] = FMI_WS_READ(b0 + (unsigned)(((wn * WNT + t) * 2) * 1024));
-      xv[t] = FMI_WS_READ(b0 + (unsigned)((AP + (wm * 4 + t) * 2) * 1024));
+      if (t < WNT) wv0[t] = lds_read_b128(b0 + (unsigned)(((wn * WNT + t) * 2) * 1024));
+      xv[t] = lds_read_b128(b0 + (unsigned)((AP + (wm * 4 + t) * 2) * 1024));
     }
 #pragma unroll
-    for (int t = 0; t < WNT; ++t) wv1[t] = FMI_WS_READ(b0 + (unsigned)(((wn * WNT + t) * 2 + 1) * 1024));
+    for (int t = 0; t < WNT; ++t) wv1[t] = lds_read_b128(b0 + (unsigned)(((wn * WNT + t) * 2 + 1) * 1024));
     // (the waits name the registers they make valid: MFMA builtins are not memory operations, so nothing else keeps
     // the compiler from scheduling a product above the wait for its operand)
     if constexpr (WNT == 4)
@@ -1044,8 +1022,9 @@ __global__ __launch_bounds__((CW + 4) * 64, CW == 8 ? 3 : WNT == 4 ? 4 : 6) void
     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
       for (int tn = 0; tn < WNT; ++tn)
-        acc[tn][tm] = FMI_WS_MFMA(wv0[tn], xv[tm], acc[tn][tm]);
-      xv[tm] = FMI_WS_READ(b0 + (unsigned)((AP + (wm * 4 + tm) * 2 + 1) * 1024));
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv0[tn]),
+                                                              *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
+      xv[tm] = lds_read_b128(b0 + (unsigned)((AP + (wm * 4 + tm) * 2 + 1) * 1024));
       __builtin_amdgcn_sched_barrier(0);   // keep each reload right behind the products that freed its register
     }
     if constexpr (WNT == 4)
@@ -1060,7 +1039,8 @@ __global__ __launch_bounds__((CW + 4) * 64, CW == 8 ? 3 : WNT == 4 ? 4 : 6) void
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int tn = 0; tn < WNT; ++tn)
-        acc[tn][tm] = FMI_WS_MFMA(wv1[tn], xv[tm], acc[tn][tm]);
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv1[tn]),
+                                                              *reinterpret_cast<bf16x8*>(&xv[tm]), acc[tn][tm], 0, 0, 0);
   }
 
   // epilogue identical to the other variants: lane holds D[n = tile*16 + g*4 + j][m = tile*16 + mi]

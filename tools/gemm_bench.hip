@@ -25,7 +25,49 @@ static inline bf16_t rnd_bf16(float scale) {
   return (bf16_t)(u >> 16);
 }
 
+// register-only MFMA loop: what the matrix cores deliver on this box (clock under load included) -- the ceiling the GEMM
+// numbers below are to be read against.  WPS waves per SIMD, each with 4 independent accumulators.
+__global__ __launch_bounds__(1024) void mfma_peak_kernel(float* out, int iters, long long* cycles) {
+  f32x4 acc[4];
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(1.0f + i * 0.5f); }
+  const long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  float v = 0.f;
+  for (int i = 0; i < 4; ++i) v += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = v;
+  if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
+}
+
+static void mfma_peak() {
+  float* out; long long* cyc; CK(hipMalloc(&out, 256 * 8 * 1024 * 4)); CK(hipMalloc(&cyc, 8));
+  for (int wps : {1, 2, 4}) {
+    const int iters = 20000;
+    dim3 grid(256 * 2), block(wps * 2 * 64);     // 2 work-groups per CU x (2 wps) waves = 4 wps waves per CU
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_peak_kernel, grid, block, 0, 0, out, iters, cyc);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(mfma_peak_kernel, grid, block, 0, 0, out, iters, cyc);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    const double flop = (double)grid.x * (block.x / 64) * iters * 16.0 * 16384.0;
+    printf("mfma peak, %d wave(s)/SIMD: %.3f ms, %.0f TF/s, %lld counter ticks = %.1f per MFMA of the wave, tick rate %.0f MHz\n", wps, ms,
+           flop / ms * 1e-9, c, (double)c / (iters * 16.0), c / (ms * 1e3));
+  }
+  hipFree(out); hipFree(cyc);
+}
+
 int main(int argc, char** argv) {
+  mfma_peak();
   const Shape shapes[] = {{"wqkv", 6144, 2560, EPI_STORE}, {"wo", 2560, 4096, EPI_RESIDUAL}, {"w1|w3", 19456, 2560, EPI_SILU}, {"w2", 2560, 9728, EPI_RESIDUAL}};
   const int Ms[] = {1600, 16384};
   const char* variants = argc > 1 ? argv[1] : "lw";
