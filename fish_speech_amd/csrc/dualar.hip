@@ -72,6 +72,9 @@ struct fmi_dualar {
   std::vector<std::vector<int>> slot_pages;
   Workspace ws;
   bf16_t *hn = nullptr, *hf = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
+  // fast_dim != dim (llama.py:665-668): packed fast_project_in weight [fast_dim][dim] + bias in the arena, and the
+  // projected hidden rows [max_batch][fast_dim] fast step 0 runs on
+  bf16_t *fpi_w = nullptr, *fpi_b = nullptr, *hfp = nullptr;
   // fast layer 0 sees fast_embeddings[code] at every codebook position >= 1, so its wqkv(rmsnorm(.)) output is a
   // pure function of the code: tabulated once with the same GEMV kernel (batch-invariant bits), gathered by the
   // sampler; 9 of the 40 fast wqkv GEMVs of a frame (31.5 MB each at the S2 shape) become 8-row gathers
@@ -121,7 +124,10 @@ int count_live(const fmi_dualar_config& c) {
 
 int validate(const fmi_dualar_config& c) {
   FMI_REQUIRE(c.dim > 0 && c.dim % 32 == 0, "dim=%d must be a positive multiple of 32", c.dim);
-  FMI_REQUIRE(c.fast_dim == c.dim, "fast_dim != dim (fast_project_in Linear) is not supported");
+  FMI_REQUIRE(c.fast_dim > 0 && c.fast_dim % 32 == 0, "fast_dim=%d must be a positive multiple of 32", c.fast_dim);
+  FMI_REQUIRE(c.fast_dim == c.dim || !c.weight_int8,
+              "fast_dim != dim with weight-only int8: the reference's int8 Linear has no bias (quantize.py:204-229), "
+              "its fast_project_in (llama.py:666) has one");
   FMI_REQUIRE(c.intermediate_size % 32 == 0 && c.fast_intermediate_size % 32 == 0, "intermediate_size %% 32");
   FMI_REQUIRE(c.head_dim == 32 || c.head_dim == 64 || c.head_dim == 128, "head_dim must be 32/64/128");
   FMI_REQUIRE(c.fast_head_dim == 32 || c.fast_head_dim == 64 || c.fast_head_dim == 128, "fast_head_dim 32/64/128");
@@ -181,6 +187,9 @@ int64_t layout(const fmi_dualar_config& c, fmi_dualar* h) {
   bf16_t* fout = (bf16_t*)take((int64_t)c.codebook_size * c.fast_dim, 2);
   bf16_t* rope = (bf16_t*)take((int64_t)c.max_seq_len * c.head_dim, 2);
   bf16_t* frope = (bf16_t*)take((int64_t)c.num_codebooks * c.fast_head_dim, 2);
+  const bool proj = c.fast_dim != c.dim;
+  bf16_t* fpiw = proj ? (bf16_t*)take((int64_t)c.fast_dim * c.dim, 2) : nullptr;
+  bf16_t* fpib = proj ? (bf16_t*)take(c.fast_dim, 2) : nullptr;
   int8_t* qfout = c.weight_int8 ? (int8_t*)take((int64_t)c.codebook_size * c.fast_dim, 1) : nullptr;
   bf16_t* sfout = c.weight_int8 ? (bf16_t*)take(c.codebook_size, 2) : nullptr;
   std::vector<LayerW> L, FL;
@@ -191,6 +200,7 @@ int64_t layout(const fmi_dualar_config& c, fmi_dualar* h) {
     h->fast_emb = femb; h->fast_norm = fnorm; h->fast_out = fout; h->rope = rope; h->fast_rope = frope;
     h->L = L; h->FL = FL; h->n_live = n_live; h->n_live_pad = n_live_pad;
     h->q_fast_out = qfout; h->s_fast_out = sfout;
+    h->fpi_w = fpiw; h->fpi_b = fpib;
   }
   return off;
 }
@@ -281,10 +291,20 @@ int ensure_rows(fmi_dualar* h, int rows) {
 // out = linear(norm?(x)) for M rows; picks the skinny (fused norm) or tiled path.
 int linear(fmi_dualar* h, const bf16_t* x, int ldx, const bf16_t* wp, const bf16_t* norm_w, const bf16_t* res,
            int ldr, bf16_t* out, int ldo, int M, int N, int K, int epi, hipStream_t s, const int8_t* wq = nullptr,
-           const bf16_t* scale = nullptr, const bf16_t* wr = nullptr) {
+           const bf16_t* scale = nullptr, const bf16_t* wr = nullptr, const bf16_t* bias = nullptr) {
   LinearArgs a{};
   a.wp = wp; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = h->cfg.norm_eps; a.res = res; a.ldr = ldr;
   a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epi = epi; a.wq = wq; a.scale = scale; a.wr = wr;
+  a.bias = bias;
+  if (bias) {   // only the skinny kernel has the bias epilogue: 16 rows per launch
+    FMI_REQUIRE(epi == EPI_STORE && !norm_w && !scale, "linear: bias goes with a plain store epilogue");
+    for (int m0 = 0; m0 < M; m0 += 16) {
+      a.x = x + (int64_t)m0 * ldx; a.out = out + (int64_t)m0 * ldo; a.M = M - m0 < 16 ? M - m0 : 16;
+      h->launches += 1;
+      FMI_CHECK(launch_linear_skinny(a, s));
+    }
+    return FMI_OK;
+  }
   // h->force_tiled: the few suffix rows of a resumed prefill must go through the kernel a full prefill of the
   // whole prompt would have used for them (the tiled GEMM: a row's bits do not depend on how many rows run along)
   if (M <= 16 && !h->force_tiled) {
@@ -374,6 +394,13 @@ int tail_head(fmi_dualar* h, const bf16_t* xl, int B, hipStream_t s) {
                 EPI_STORE, s);
 }
 
+// llama.py:827: hidden_states = fast_project_in(hidden_states) -- Linear(dim, fast_dim) with bias, only when fast_dim != dim
+int project_fast_in(fmi_dualar* h, const bf16_t* hid, bf16_t* out, int B, hipStream_t s) {
+  const fmi_dualar_config& c = h->cfg;
+  return linear(h, hid, c.dim, h->fpi_w, nullptr, nullptr, 0, out, c.fast_dim, B, c.fast_dim, c.dim, EPI_STORE, s, nullptr,
+                nullptr, nullptr, h->fpi_b);
+}
+
 int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStream_t s) {
   const fmi_dualar_config& c = h->cfg;
   const int dim = c.dim;
@@ -389,8 +416,13 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   h->launches += 1;
   // fast step 0 on the hidden state; its logits are discarded (inference.py:148-149)
   bf16_t* f0 = h->hf;
-  if (!c.norm_fastlayer_input)
+  if (h->fpi_w) {        // fast_dim != dim: step 0 runs on the projected hidden rows
+    FMI_CHECK(project_fast_in(h, c.norm_fastlayer_input ? h->hn : xl, h->hfp, B, s));
+    f0 = h->hfp + (int64_t)h->max_batch * c.fast_dim;   // step 0 transforms its input in place: keep the tap
+    FMI_CHECK_HIP(hipMemcpyAsync(f0, h->hfp, (size_t)B * c.fast_dim * 2, hipMemcpyDeviceToDevice, s));
+  } else if (!c.norm_fastlayer_input) {
     FMI_CHECK_HIP(hipMemcpyAsync(h->hf, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
+  }
   // Fast step 0 exists only to put the hidden state's K/V into slot 0 of every fast layer: its logits are
   // discarded (inference.py:148-149), so the last layer's wo / FFN output feeds nothing and is skipped.
   for (int i = 0; i < c.n_fast_layer; ++i)
@@ -602,7 +634,7 @@ void fmi_dualar_destroy(fmi_dualar* h) {
   void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
                   h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
                   h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging, h->staging2,
-                  h->qkv0_tab, h->qkv0_pre, h->attn_part};
+                  h->qkv0_tab, h->qkv0_pre, h->attn_part, h->hfp};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (void* p : h->row_copies) hipFree(p);
@@ -645,6 +677,8 @@ int fmi_dualar_load_tensor(fmi_dualar* h, const char* name_c, const void* src, i
   else if (name == "fast_embeddings.weight") { FMI_CHECK(expect(c.codebook_size, c.fast_dim)); rc = copy(h->fast_emb); }
   else if (name == "fast_norm.weight") { FMI_CHECK(expect(1, c.fast_dim)); rc = copy(h->fast_norm); }
   else if (name == "fast_output.weight") { FMI_CHECK(expect(c.codebook_size, c.fast_dim)); rc = launch_pack_weight(dsrc, h->fast_out, (int)rows, (int)cols, 0, s); }
+  else if (name == "fast_project_in.weight" && h->fpi_w) { FMI_CHECK(expect(c.fast_dim, c.dim)); rc = launch_pack_weight(dsrc, h->fpi_w, (int)rows, (int)cols, 0, s); }
+  else if (name == "fast_project_in.bias" && h->fpi_b) { FMI_CHECK(expect(1, c.fast_dim)); rc = copy(h->fpi_b); }
   else if (name == "freqs_cis") { FMI_CHECK(expect(c.max_seq_len, c.head_dim)); rc = copy(h->rope); h->rope_loaded = true; }
   else if (name == "fast_freqs_cis") { FMI_CHECK(expect(c.num_codebooks, c.fast_head_dim)); rc = copy(h->fast_rope); h->fast_rope_loaded = true; }
   else {
@@ -752,6 +786,10 @@ int fmi_dualar_finalize_weights(fmi_dualar* h, void* stream) {
   // completeness check
   std::vector<std::string> need = {"embeddings.weight", "codebook_embeddings.weight", "norm.weight",
                                    "fast_embeddings.weight", "fast_norm.weight", "fast_output.weight"};
+  if (c.fast_dim != c.dim) {
+    need.push_back("fast_project_in.weight");
+    need.push_back("fast_project_in.bias");
+  }
   auto add_layer = [&](const std::string& pre, bool qk) {
     for (const char* sfx : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w1.weight",
                             "feed_forward.w3.weight", "feed_forward.w2.weight", "attention_norm.weight",
@@ -855,6 +893,7 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
   FMI_CHECK(dev_alloc(&h->hn, (int64_t)max_batch * c.dim));
   FMI_CHECK(dev_alloc(&h->xl, (int64_t)max_batch * c.dim));
   FMI_CHECK(dev_alloc(&h->hf, (int64_t)max_batch * c.dim));
+  if (c.fast_dim != c.dim) FMI_CHECK(dev_alloc(&h->hfp, (int64_t)2 * max_batch * c.fast_dim));   // parity tap | step-0 work copy
   FMI_CHECK(dev_alloc(&h->xf, (int64_t)max_batch * c.fast_dim));
   FMI_CHECK(dev_alloc(&h->logits, (int64_t)max_batch * h->n_live_pad));
   FMI_CHECK(dev_alloc(&h->flogits, (int64_t)max_batch * c.codebook_size));
@@ -1174,8 +1213,13 @@ int fmi_dualar_forward_slow(fmi_dualar* h, int slot, const int32_t* x_dev, int S
     FMI_CHECK_HIP(hipMemcpyAsync(logits_out_dev, h->logits, (size_t)h->n_live * 2, hipMemcpyDeviceToDevice, s));
   if (hidden_out_dev) {
     // llama.py:459-461: hidden_states = slow_out (normed) if norm_fastlayer_input else the un-normed last row
+    // (llama.py:827: DualARTransformer.forward_generate hands back fast_project_in(hidden): fast_dim values then)
     const bf16_t* hid = h->cfg.norm_fastlayer_input ? h->hn : ((S > 1 || pos0 == 0) ? h->xl : h->ws.x);
-    FMI_CHECK_HIP(hipMemcpyAsync(hidden_out_dev, hid, (size_t)h->cfg.dim * 2, hipMemcpyDeviceToDevice, s));
+    if (h->fpi_w) {
+      FMI_CHECK(project_fast_in(h, hid, h->hfp, 1, s));
+      hid = h->hfp;
+    }
+    FMI_CHECK_HIP(hipMemcpyAsync(hidden_out_dev, hid, (size_t)h->cfg.fast_dim * 2, hipMemcpyDeviceToDevice, s));
   }
   return sync_out(h, stream);
 }
@@ -1218,7 +1262,7 @@ int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* l
   if (n_live) *n_live = h->n_live;
   if (ld_logits) *ld_logits = h->n_live_pad;
   if (live_ids) *live_ids = h->live_ids;
-  if (hidden) *hidden = h->hn;
+  if (hidden) *hidden = h->fpi_w ? h->hfp : h->hn;   // what the fast transformer is handed (llama.py:827)
   if (fast_logits) *fast_logits = h->flogits;
   return FMI_OK;
 }

@@ -64,6 +64,9 @@ struct LinearArgs {
   // row-balanced decode copy of `wp` (launch_repack_rows; nullptr = none): streamed instead of `wp` by the M <= 8
   // decode GEMV, one work-group per CU-sized share of the rows.
   const bf16_t* wr;
+  // nn.Linear bias [N] (only fast_project_in has one, llama.py:666): out = bf16(acc + bias), ONE rounding like torch's
+  // addmm; skinny kernel, EPI_STORE only
+  const bf16_t* bias;
 };
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s);  // M <= 16
 

@@ -573,6 +573,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
         float sacc = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sacc += red[w][t][ridx];
+        if (EPI == EPI_STORE && a.bias) sacc += bf2f(a.bias[(tile0 + t) * ROWS + r]);   // Linear bias: added before the ONE rounding
         v[t] = rbf(sacc);   // the linear's bf16 output ...
         if (a.scale) v[t] = rbf(v[t] * bf2f(a.scale[(tile0 + t) * 16 + r]));  // ... times the int8 row scale
       }
@@ -1087,6 +1088,7 @@ __global__ __launch_bounds__((CW + 4) * 64, CW == 8 ? 3 : WNT == 4 ? 4 : 6) void
 
 int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, int variant) {
   FMI_REQUIRE(a.norm_w == nullptr, "linear_tiled: fused norm not supported (use rmsnorm_rows)");
+  FMI_REQUIRE(a.bias == nullptr, "linear_tiled: no bias epilogue (skinny kernel only)");
   FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0 && a.ldo % 4 == 0, "linear_tiled: bad shape");
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_tiled: SwiGLU needs N %% 32");
   dim3 grid(cdiv(a.N / 16, 8), cdiv(a.M, 128)), block(256);

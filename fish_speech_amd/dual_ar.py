@@ -145,6 +145,9 @@ def expected_state_shapes(cfg: "DualARConfig") -> Dict[str, tuple]:
            "codebook_embeddings.weight": (cfg.codebook_size * cfg.num_codebooks, cfg.dim),
            "norm.weight": (cfg.dim,), "fast_embeddings.weight": (cfg.codebook_size, cfg.fast_dim),
            "fast_norm.weight": (cfg.fast_dim,), "fast_output.weight": (cfg.codebook_size, cfg.fast_dim)}
+    if cfg.fast_dim != cfg.dim:      # llama.py:665-666: Linear(dim, fast_dim) with bias between the two transformers
+        out["fast_project_in.weight"] = (cfg.fast_dim, cfg.dim)
+        out["fast_project_in.bias"] = (cfg.fast_dim,)
     for i in range(cfg.n_layer):
         out.update(block(f"layers.{i}", cfg.dim, cfg.n_head, cfg.n_local_heads, cfg.head_dim,
                          cfg.intermediate_size, cfg.attention_qk_norm))
@@ -375,7 +378,8 @@ class MiDualAR:
     def forward_generate(self, x: torch.Tensor, input_pos: Optional[torch.Tensor] = None, audio_masks=None,
                          audio_parts=None) -> "ForwardResult":
         """x: (1, 1+ncb, S) integer.  Returns logits (1, 1, vocab) -- finite only on the constrained rows,
-        which is what survives the reference's semantic_logit_bias anyway -- and hidden_states (1, 1, dim)."""
+        which is what survives the reference's semantic_logit_bias anyway -- and hidden_states (1, 1, fast_dim):
+        what the fast transformer is handed, i.e. after `fast_project_in` when fast_dim != dim (llama.py:827)."""
         cfg = self.config
         if not self._cache_setup_done:
             self.setup_caches(1, cfg.max_seq_len)
@@ -386,7 +390,7 @@ class MiDualAR:
         self._cached_prompt.pop(0, None)           # slot 0's K/V are rewritten: a retained prefix is stale now
         ids = self._table(1, torch.int32).view(-1).long()
         live = torch.empty(ids.numel(), dtype=torch.bfloat16, device=self.device)
-        hidden = torch.empty(cfg.dim, dtype=torch.bfloat16, device=self.device)
+        hidden = torch.empty(cfg.fast_dim, dtype=torch.bfloat16, device=self.device)
         check(self.lib.fmi_dualar_forward_slow(self._h, 0, C.c_void_p(xs.data_ptr()), int(xs.shape[0]), pos0,
                                                C.c_void_p(live.data_ptr()), C.c_void_p(hidden.data_ptr()), self._stream()))
         logits = torch.full((1, 1, cfg.vocab_size), float("-inf"), dtype=torch.bfloat16, device=self.device)
@@ -545,7 +549,8 @@ class MiDualAR:
 
     # ---- parity taps
     def debug_taps(self, B: int = 1):
-        """(slow live-row logits (B, n_live) bf16, live vocab ids, normed hidden (B, dim), last fast logits)."""
+        """(slow live-row logits (B, n_live) bf16, live vocab ids, the hidden rows the fast transformer is handed
+        (B, fast_dim), last fast logits)."""
         p_log, p_ids, p_hid, p_fl = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         n_live, ld = C.c_int(), C.c_int()
         check(self.lib.fmi_dualar_debug_ptrs(self._h, C.byref(p_log), C.byref(n_live), C.byref(ld), C.byref(p_ids),
@@ -554,7 +559,7 @@ class MiDualAR:
         cfg = self.config
         logits = _from_ptr(p_log.value, (B, ld.value), torch.bfloat16, self.device)[:, : n_live.value].clone()
         ids = _from_ptr(p_ids.value, (n_live.value,), torch.int32, self.device).clone()
-        hidden = _from_ptr(p_hid.value, (B, cfg.dim), torch.bfloat16, self.device).clone()
+        hidden = _from_ptr(p_hid.value, (B, cfg.fast_dim), torch.bfloat16, self.device).clone()   # projected when fast_dim != dim
         fl = _from_ptr(p_fl.value, (B, cfg.codebook_size), torch.bfloat16, self.device).clone()
         return logits, ids, hidden, fl
 

@@ -148,7 +148,8 @@ int fmi_dualar_step(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int po
 /* The model-object seam of SURVEY.md 8b, for callers that keep the reference's own
  * decode_one_token_ar: BaseTransformer.forward_generate (llama.py:390-466, slow transformer + final norm
  * + tied head; logits bf16 over the n_live constrained rows -- every other vocabulary row is -inf after
- * semantic_logit_bias, inference.py:310-320 -- hidden bf16 [dim]) and
+ * semantic_logit_bias, inference.py:310-320 -- hidden bf16 [fast_dim]: DualARTransformer.forward_generate's
+ * fast_project_in Linear(dim, fast_dim) with bias is applied when fast_dim != dim, llama.py:665-668,827) and
  * DualARTransformer.forward_generate_fast (llama.py:799-817; hidden bf16 [fast_dim] at codebook
  * position pos -> logits bf16 [codebook_size]).  Batch 1 like the reference. */
 int fmi_dualar_forward_slow(fmi_dualar* h, int slot, const int32_t* x_dev, int S, int pos0,
@@ -161,7 +162,8 @@ int fmi_dualar_table_ptr(fmi_dualar* h, int which, void** ptr, int* rows, int* c
 
 /* Debug / parity taps (device pointers owned by the library, valid until the next call):
  * live-row logits of the last slow step (bf16, [B][n_live_padded]), the vocab id of each
- * live row (int32 [n_live]), the normed hidden (bf16 [B][dim]) and the fast logits of the
+ * live row (int32 [n_live]), the hidden rows handed to the fast transformer (bf16 [B][fast_dim]: the normed hidden,
+ * projected when fast_dim != dim) and the fast logits of the
  * last fast step (bf16 [B][codebook_size]). */
 int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* ld_logits,
                           void** live_ids, void** hidden, void** fast_logits);

@@ -96,8 +96,15 @@ class DualARConfig:
             semantic_end_id=self.semantic_end_id,
             scale_codebook_embeddings=self.scale_codebook_embeddings,
             norm_fastlayer_input=self.norm_fastlayer_input, n_fast_layer=self.n_fast_layer,
-            tie_word_embeddings=True,
+            tie_word_embeddings=True, fast_dim=self.fast_dim, fast_n_head=self.fast_n_head,
+            fast_n_local_heads=self.fast_n_local_heads, fast_head_dim=self.fast_head_dim,
+            fast_intermediate_size=self.fast_intermediate_size, fast_attention_qk_norm=self.fast_attention_qk_norm,
         )
+
+    @property
+    def has_fast_project_in(self) -> bool:
+        """llama.py:665-668: a Linear(dim, fast_dim) WITH bias when the fast transformer is narrower / wider."""
+        return self.fast_dim != self.dim
 
 
 def s2_pro_shaped_config(max_seq_len: int = 4096) -> DualARConfig:
@@ -141,6 +148,9 @@ def state_shapes(cfg: DualARConfig) -> Dict[str, tuple]:
         "fast_norm.weight": (cfg.fast_dim,),
         "fast_output.weight": (cfg.codebook_size, cfg.fast_dim),
     }
+    if cfg.has_fast_project_in:   # llama.py:665-666
+        s["fast_project_in.weight"] = (cfg.fast_dim, cfg.dim)
+        s["fast_project_in.bias"] = (cfg.fast_dim,)
     for i in range(cfg.n_layer):
         s.update(_block_keys(f"layers.{i}", cfg.dim, cfg.n_head, cfg.n_local_heads, cfg.head_dim,
                              cfg.intermediate_size, cfg.attention_qk_norm))
@@ -161,7 +171,9 @@ def make_synthetic_state(cfg: DualARConfig, seed: int = 0, dtype=torch.bfloat16,
     g = torch.Generator(device="cpu").manual_seed(seed)
     out = {}
     for name, shape in state_shapes(cfg).items():
-        if len(shape) == 1:
+        if name.endswith(".bias"):
+            t = matrix_std * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
         else:
             t = matrix_std * torch.randn(shape, generator=g)
@@ -514,6 +526,8 @@ class DualAROracle:
         slow_out = rms_norm(x, self.w["norm.weight"], cfg.norm_eps)
         logits = F.linear(slow_out, self.w["embeddings.weight"])  # tied head, llama.py:454-455
         hidden = slow_out if cfg.norm_fastlayer_input else x
+        if cfg.has_fast_project_in:   # llama.py:827 (DualARTransformer.forward_generate)
+            hidden = F.linear(hidden, self.w["fast_project_in.weight"], self.w["fast_project_in.bias"])
         return logits, hidden
 
     # llama.py:799-817

@@ -156,6 +156,9 @@ PEAKY_CASES = {
     "mid_peaky": (_MID, dict(seed=93, emb_gain=2.5, slow_gain=3.0, fast_gain=2.5), (40, 12, 3), 48, (0.7, 0.7, 1), 1234),
     # the same model quantised by the reference's own WeightOnlyInt8QuantHandler (name suffix _int8)
     "tiny_peaky_int8": ({}, dict(seed=1, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5), (24, 8, 1), 48, (0.7, 0.7, 1), 1234),
+    # fast_dim != dim: the reference's fast_project_in Linear(dim, fast_dim) with bias (llama.py:665-668,827)
+    "tiny_projin": (dict(fast_dim=96, fast_n_head=3, fast_n_local_heads=1, fast_head_dim=32, fast_intermediate_size=192),
+                    dict(seed=3, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5), (24, 8, 1), 64, (0.7, 0.7, 1), 1234),
     "tiny_sampled": ({}, dict(seed=3, emb_gain=6.0, slow_gain=2.0, fast_gain=8.0, hot=(1.0, 0.95, 0.93), hot_every=3),
                      (24, 8, 3), 40, (0.7, 0.9, 30), 67),
 }
@@ -167,7 +170,10 @@ def gen_dualar_peaky():
 
     from .search_golden import sampled_run_is_robust
 
+    only = os.environ.get("PEAKY_ONLY")
     for name, (kw, skw, (T, nsem, pseed), max_new, (temp, top_p, top_k), useed) in PEAKY_CASES.items():
+        if only and name != only:
+            continue
         cfg = O.DualARConfig(**kw)
         state = O.make_peaky_state(cfg, **skw)
         prompt = O.make_prompt(cfg, T, seed=pseed, n_semantic=nsem)

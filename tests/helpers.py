@@ -29,7 +29,7 @@ def load_dualar_case(name: str):
     return cfg, state, z
 
 
-PEAKY_GREEDY = ["tiny_peaky", "tiny_peaky_eos", "mid_peaky"]
+PEAKY_GREEDY = ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_projin"]   # tiny_projin: fast_dim != dim (fast_project_in)
 PEAKY_ALL = PEAKY_GREEDY + ["tiny_sampled"]
 
 

@@ -284,7 +284,7 @@ def test_generate_free_running_vs_reference_golden(case):
     assert np.array_equal(got[:, :T], want[:, :T])
 
 
-@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled"])
+@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled", "tiny_projin"])
 def test_generate_full_sequence_equals_reference_on_well_conditioned_fixtures(case):
     """STRICT index parity: prefill + hipGraph decode loop, free-running, against the token
     sequence the UNMODIFIED reference's generate() (inference.py:243-359) wrote for the well-conditioned fixtures
@@ -310,7 +310,7 @@ def test_generate_full_sequence_equals_reference_on_well_conditioned_fixtures(ca
     assert np.array_equal(got2, want)
 
 
-@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky"])
+@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_projin"])
 def test_teacher_forced_exact_decisions_on_well_conditioned_fixtures(case):
     """Teacher-forced through the decode_one_token seam with the reference's history: taps within the bf16 noise
     bound AND every single decision equal to the reference's (exact == decisions)."""
@@ -914,6 +914,45 @@ def test_forward_generate_hidden_is_unnormed_without_norm_fastlayer_input():
         rel = float((got.float() - want.float()).norm() / want.float().norm())
         rel_n = float((got.float() - normed.float()).norm() / normed.float().norm())
         assert rel <= 2e-2 < rel_n, (rel, rel_n)
+
+
+@pytest.mark.parametrize("norm_in", [True, False])
+def test_fast_project_in_when_fast_dim_differs(norm_in):
+    """llama.py:665-668,827: with fast_dim != dim the hidden state goes through Linear(dim, fast_dim) WITH bias before
+    the fast transformer; `forward_generate` hands back the projected rows (prefill and single-token calls), the
+    bias is added before the one bf16 rounding (torch's addmm), a batch of ragged prompts equals the single runs,
+    and int8 + projection is refused like upstream's bias-free int8 Linear would."""
+    from fish_speech_amd.dual_ar import generate, generate_batch
+
+    kw = dict(fast_dim=96, fast_n_head=3, fast_n_local_heads=1, fast_head_dim=32, fast_intermediate_size=192)
+    cfg = O.DualARConfig(norm_fastlayer_input=norm_in, **kw)
+    state = O.make_synthetic_state(cfg, seed=6, head_gain=8.0)
+    state["fast_project_in.bias"] = (state["fast_project_in.bias"].float() * 20).bfloat16()   # make the bias matter
+    model = _make_model(cfg, state)
+    orc = O.DualAROracle(cfg, state)
+    orc.setup_caches(1, cfg.max_seq_len)
+    p = O.make_prompt(cfg, 11, seed=2, n_semantic=4)
+    ncb1 = cfg.num_codebooks + 1
+    for x, pos in ((p.view(1, ncb1, -1), torch.arange(11)), (p[:, -1:].reshape(1, ncb1, 1), torch.tensor([11]))):
+        _, want = orc.forward_generate(x, pos, math_backend=True)
+        got = model.forward_generate(x.to(DEV), pos.to(DEV)).hidden_states.cpu()
+        assert got.shape[-1] == 96 == want.shape[-1]
+        nobias = want.float() - state["fast_project_in.bias"].float()
+        rel = float((got.float() - want.float()).norm() / want.float().norm())
+        rel_nb = float((got.float() - nobias).norm() / want.float().norm())
+        assert rel <= 2e-2 < rel_nb, (rel, rel_nb)
+    prompts = [O.make_prompt(cfg, T, seed=30 + T, n_semantic=4) for T in (9, 17, 5)]
+    single = [generate(model=model, prompt=q, max_new_tokens=6, temperature=0.7, top_p=0.7, top_k=1, seed=3) for q in prompts]
+    batch = generate_batch(model=model, prompts=prompts, max_new_tokens=6, temperature=0.7, top_p=0.7, top_k=1, seeds=[3, 3, 3])
+    for a, b in zip(single, batch):
+        assert torch.equal(a, b)
+    from fish_speech_amd._lib import FishmiError
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR
+
+    pc = DualARConfig.from_any(cfg, cfg.im_end_id)
+    pc.weight_int8 = True
+    with pytest.raises(FishmiError, match="int8"):
+        MiDualAR(pc, device=DEV, im_end_id=cfg.im_end_id)
 
 
 def test_decode_one_token_accepts_only_the_generate_bias():

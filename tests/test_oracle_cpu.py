@@ -110,6 +110,25 @@ def test_oracle_bit_exact_vs_reference_fp32_and_bf16():
         assert torch.equal(ref, got.long())
 
 
+PROJIN = dict(fast_dim=96, fast_n_head=3, fast_n_local_heads=1, fast_head_dim=32, fast_intermediate_size=192)
+
+
+def test_oracle_fast_project_in_bit_exact_vs_reference():
+    """fast_dim != dim: the reference puts a Linear(dim, fast_dim) WITH bias between the two transformers
+    (llama.py:665-668,827); the oracle's restatement equals the unmodified reference's generate() bit for bit."""
+    from oracle.gen_golden import _ref_generate
+
+    cfg = O.DualARConfig(**PROJIN)
+    assert cfg.has_fast_project_in
+    for dtype in (torch.float32, torch.bfloat16):
+        st = O.make_synthetic_state(cfg, seed=5, dtype=dtype, head_gain=8.0)
+        assert st["fast_project_in.weight"].shape == (96, 128) and st["fast_project_in.bias"].shape == (96,)
+        prompt = O.make_prompt(cfg, 19, seed=6, n_semantic=6)
+        ref = _ref_generate(cfg, st, prompt, 10, 30, O.FmiUniform(77))
+        got = O.generate(O.DualAROracle(cfg, st), prompt, 10, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(77))
+        assert torch.equal(ref, got.long())
+
+
 def test_int8_weight_only_oracle_vs_reference_golden():
     """§8f #2 groundwork: the reference's weight-only int8 path (tools/llama/quantize.py:186-229 -- per-row
     symmetric quantisation, `F.linear(x, w.to(bf16)) * scales`) restated in the oracle, against the fixture the
