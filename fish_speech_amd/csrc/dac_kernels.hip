@@ -360,10 +360,16 @@ int launch_split_conv_planes(const float* w_packed, bf16_t* wb, int tapgroups, i
 // TAPS = 7: the tap loop is unrolled (operand reads of the next tap overlap the MFMAs of the current one).
 // TC > 0: the weight tile is brought in TC taps at a time (k = 7 as 4 + 3): a third of the LDS per work-group, so two
 // or three work-groups share a CU and one's staging phase hides behind another's matrix phase.
-template <int MT, int NT, int G, int NP, int TAPS, int TC>
+// PH (transposed convs): the MT row tiles of a work-group are MT consecutive PHASES of the same 32 output channels
+// instead of 32 * MT channels of one phase.  A lane then holds, for its input column q, the output columns
+// q * stride + phase0 .. + MT - 1 of a channel: it stores them as one vector, and the operand planes of MT consecutive
+// output columns -- with one phase per work-group every work-group wrote every stride-th float / 32-byte plane entry
+// of lines that stride work-groups shared.  Same products in the same order per output element.
+template <int MT, int NT, int G, int NP, int TAPS, int TC, bool PH = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int ncols, int wx, int tap_off0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CO_T = MT * 32, TT = 4 * NT * 32;
+  constexpr int CO_W = PH ? 32 : CO_T;        // output channels per work-group
   const int taps = TAPS > 0 ? TAPS : a.w.taps;
   const int wt = TC > 0 ? TC : taps;                        // taps resident in Ws at a time
   char* Ws = reinterpret_cast<char*>(smem);                 // [wt][G][NP][CO_T] rows of 32 bytes
@@ -374,13 +380,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lk = lane >> 5;
   const int q0 = blockIdx.x * TT;
-  const int co0 = blockIdx.y * CO_T;
-  const int b = blockIdx.z / a.w.phases, phase = blockIdx.z % a.w.phases;
+  const int co0 = blockIdx.y * CO_W;
+  const int zph = PH ? a.w.phases / MT : a.w.phases;          // phase groups per utterance
+  const int b = blockIdx.z / zph, phase = (blockIdx.z % zph) * (PH ? MT : 1);
   const int c0 = q0 * a.x_stride + a.tap_base - tap_off0;
   const float* xb = a.x + (int64_t)b * a.w.cin * a.lin;
   const int cgs = a.w.cin_pad16 >> 4;
   // plane 0 of (phase, tap 0, group 0), rows from co0
   const bf16_t* wph = a.w.wb + ((((int64_t)phase * taps * cgs * 3) * a.w.cout_pad + co0) << 4);
+  const int64_t ph_bytes = ((int64_t)taps * cgs * 3 * a.w.cout_pad) << 5;   // one phase of the packed weight, in bytes
   const bool do_snake = a.snake_alpha != nullptr;
 
   // NP = 1: bf16 operands (autocast), one product.  NP = 2: fp16 split, acc = hi*hi, acx = hi*lo16 + lo16*hi.
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
       const int pl = row % NP, tg = row / NP;
       const int tp = t0 + tg / G, g = tg % G;
       const char* gsrc = reinterpret_cast<const char*>(wph + (((((int64_t)tp * cgs + cg0 + g) * 3 + SLOT0 + pl) * a.w.cout_pad) << 4)) +
-                         pc * 1024 + lane * 16;
+                         (PH ? pc * ph_bytes : (int64_t)pc * 1024) + lane * 16;   // row tile pc: next 32 rows, or next phase
       __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)(Ws + p * 1024), 16, 0, 0);
     }
   };
@@ -491,47 +499,57 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
       }
     }
     __syncthreads();   // drains the LDS-DMA too (vmcnt(0) is part of the barrier's fence)
-#pragma unroll(TAPS > 0 ? TAPS : 1)
-    for (int tp = 0; tp < taps; ++tp) {
-      const int tl = TC > 0 ? tp % TC : tp;      // tap's place in the resident part of the weight tile
-      if (TC > 0 && tp > 0 && tl == 0) {         // next part: everybody is done with the resident one
-        __syncthreads();
-        fetch_w(cg0, tp, taps - tp < TC ? taps - tp : TC);
-        __syncthreads();
+    // products of (resident tap slot tl, tap offset xoff, channel group g of the step)
+    auto mm = [&](int tl, int xoff, int g) {
+      bf16x8 af[NP][MT], bf[NP][NT];
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          af[pl][i] = *reinterpret_cast<const bf16x8*>(a_lane + (((tl * G + g) * NP + pl) * CO_T + i * 32) * 32);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int c = (qw + j * 32 + li) * a.x_stride + xoff;
+          bf[pl][j] = *reinterpret_cast<const bf16x8*>(Xs + ((int64_t)(g * NP + pl) * wx + c) * 32 + (((lk ^ (c >> 3)) & 1) << 4));
+        }
       }
-      const int xoff = tap_off0 + tp * a.tap_step;
+      if constexpr (NP == 2) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        bf16x8 af[NP][MT], bf[NP][NT];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-            af[pl][i] = *reinterpret_cast<const bf16x8*>(a_lane + (((tl * G + g) * NP + pl) * CO_T + i * 32) * 32);
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            const int c = (qw + j * 32 + li) * a.x_stride + xoff;
-            bf[pl][j] = *reinterpret_cast<const bf16x8*>(Xs + ((int64_t)(g * NP + pl) * wx + c) * 32 + (((lk ^ (c >> 3)) & 1) << 4));
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(&af[0][i]), a1 = *reinterpret_cast<const f16x8*>(&af[1][i]);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(&bf[0][j]), b1 = *reinterpret_cast<const f16x8*>(&bf[1][j]);
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acx[i][j], 0, 0, 0);
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acx[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
           }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+      }
+    };
+    if constexpr (TAPS == 0 && TC == 0 && G > 1) {
+      // several channel groups per step with more than one tap (the transposed convs): group-major, so that an
+      // output element accumulates (group, tap) in the order the one-group-per-step kernel does -- same bits
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        for (int tp = 0; tp < taps; ++tp) mm(tp, tap_off0 + tp * a.tap_step, g);
+    } else {
+#pragma unroll(TAPS > 0 ? TAPS : 1)
+      for (int tp = 0; tp < taps; ++tp) {
+        const int tl = TC > 0 ? tp % TC : tp;      // tap's place in the resident part of the weight tile
+        if (TC > 0 && tp > 0 && tl == 0) {         // next part: everybody is done with the resident one
+          __syncthreads();
+          fetch_w(cg0, tp, taps - tp < TC ? taps - tp : TC);
+          __syncthreads();
         }
-        if constexpr (NP == 2) {
+        const int xoff = tap_off0 + tp * a.tap_step;
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const f16x8 a0 = *reinterpret_cast<const f16x8*>(&af[0][i]), a1 = *reinterpret_cast<const f16x8*>(&af[1][i]);
-              const f16x8 b0 = *reinterpret_cast<const f16x8*>(&bf[0][j]), b1 = *reinterpret_cast<const f16x8*>(&bf[1][j]);
-              acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acx[i][j], 0, 0, 0);
-              acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acx[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
-        }
+        for (int g = 0; g < G; ++g) mm(tl, xoff, g);
       }
     }
     __syncthreads();
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
   float* sb = smem;
   float* sg = smem + CO_T;
   const int co_last = a.w.cout - 1;
-  if (tid < CO_T) {
+  if (tid < CO_W) {
     const int co = min(co0 + tid, co_last);
     sb[tid] = a.w.bias ? (NP == 1 ? rbf(a.w.bias[co]) : a.w.bias[co]) : 0.f;
     sg[tid] = a.gamma ? a.gamma[co] : 1.f;
@@ -550,62 +568,127 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
   float* ob = a.out ? a.out + (int64_t)b * a.w.cout * a.lout : nullptr;
   const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : ob;
   const bool has_res = a.res != nullptr;
+  auto finish = [&](float accv, float acxv, float bias, float gam, float resv) {
+    float v = (NP == 2 ? accv + acxv * (1.0f / F16_LO_SCALE) : accv) + bias;
+    if (NP == 1) v = rbf(v);   // autocast(bf16): the conv / linear returns bf16 (bias already bf16-rounded)
+    if (a.act == ACT_GELU) {
+      v = gelu_f(v);
+      if (NP == 1) v = rbf(v);  // GELU of a bf16 tensor is a bf16 tensor
+    }
+    return v * gam + resv;      // LayerScale / ConvNeXt gamma (fp32 parameter) and the residual promote to fp32
+  };
+  // operand planes for the consumer: Snake of ITS alpha, split, 4 channels = 8 bytes
+  auto put_planes = [&](const float* o4, int co, int col) {
+    float t[4] = {o4[0], o4[1], o4[2], o4[3]};
+    if (a.next_alpha) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+      for (int e = 0; e < 4; ++e) t[e] = snake_f(t[e], a.next_alpha[co + e]);
+    }
+    uint32_t h0, l0 = 0, h1, l1 = 0;
+    if (NP == 2) {
+      split2_f16_pk(t[0], t[1], h0, l0);
+      split2_f16_pk(t[2], t[3], h1, l1);
+    } else {
+      h0 = cvt_pk_bf16_f32(t[0], t[1]);
+      h1 = cvt_pk_bf16_f32(t[2], t[3]);
+    }
+    char* dst = reinterpret_cast<char*>(a.outp) +
+                ((((int64_t)b * (a.w.cout >> 4) + (co >> 4)) * NP) * a.lout + col) * 32 + (co & 15) * 2;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    if (NP == 2) *reinterpret_cast<uint2*>(dst + (int64_t)a.lout * 32) = make_uint2(l0, l1);
+  };
+  if constexpr (PH) {
+    // tile i = phase + i: the lane's MT values of (channel, input column q) are MT consecutive output columns
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int q = q0 + qw + j * 32 + li;
       const bool live = q < ncols;
-      const int col = (live ? q : 0) * a.out_stride + phase;
-      const int row0 = i * 32 + 4 * lk;
-      float rv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = min(co0 + row0 + 8 * (r >> 2) + (r & 3), co_last);
-        rv[r] = has_res ? rb[co * a.lout + col] : 0.f;
-      }
+      const int col0 = (live ? q : 0) * a.out_stride + phase;
+      const int row0 = 4 * lk;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        float o4[4];
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb + row0 + 8 * r4);
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg + row0 + 8 * r4);
+        const int co = co0 + row0 + 8 * r4;
+        float o[MT][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = r4 * 4 + e;
-          float v = (NP == 2 ? acc[i][j][r] + acx[i][j][r] * (1.0f / F16_LO_SCALE) : acc[i][j][r]) + b4[e];
-          if (NP == 1) v = rbf(v);   // autocast(bf16): the conv / linear returns bf16 (bias already bf16-rounded)
-          if (a.act == ACT_GELU) {
-            v = gelu_f(v);
-            if (NP == 1) v = rbf(v);  // GELU of a bf16 tensor is a bf16 tensor
-          }
-          v = v * g4[e] + rv[r];     // LayerScale / ConvNeXt gamma (fp32 parameter) and the residual promote to fp32
-          const int co = co0 + row0 + 8 * r4 + e;
-          if (a.out && live && co <= co_last) ob[co * a.lout + col] = v;
-          o4[e] = v;
-        }
-        if (a.outp) {   // operand planes for the consumer: Snake of ITS alpha, three-way split, 4 channels = 8 bytes
-          const int co = co0 + row0 + 8 * r4;
-          if (live && co + 3 <= co_last) {
-            if (a.next_alpha) {
+          const int coe = min(co + e, co_last);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o4[e] = snake_f(o4[e], a.next_alpha[co + e]);
-            }
-            uint32_t h0, l0 = 0, h1, l1 = 0;
-            if (NP == 2) {
-              split2_f16_pk(o4[0], o4[1], h0, l0);
-              split2_f16_pk(o4[2], o4[3], h1, l1);
-            } else {
-              h0 = cvt_pk_bf16_f32(o4[0], o4[1]);
-              h1 = cvt_pk_bf16_f32(o4[2], o4[3]);
-            }
-            char* dst = reinterpret_cast<char*>(a.outp) +
-                        ((((int64_t)b * (a.w.cout >> 4) + (co >> 4)) * NP) * a.lout + col) * 32 + (co & 15) * 2;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-            if (NP == 2) *reinterpret_cast<uint2*>(dst + (int64_t)a.lout * 32) = make_uint2(l0, l1);
+          for (int i = 0; i < MT; ++i) {
+            const float rv = has_res ? rb[(int64_t)coe * a.lout + col0 + i] : 0.f;
+            o[i][e] = finish(acc[i][j][r], NP == 2 ? acx[i][j][r] : 0.f, b4[e], g4[e], rv);
           }
+          if (a.out && live && co + e <= co_last) {
+            float* dst = ob + (int64_t)(co + e) * a.lout + col0;
+            if constexpr (MT == 4) *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0][e], o[1][e], o[2][e], o[3][e]};
+            else if constexpr (MT == 2) *reinterpret_cast<float2*>(dst) = make_float2(o[0][e], o[1][e]);
+            else {
+#pragma unroll
+              for (int i = 0; i < MT; ++i) dst[i] = o[i][e];
+            }
+          }
+        }
+        if (a.outp && live && co + 3 <= co_last) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) put_planes(o[i], co, col0 + i);
         }
       }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int q = q0 + qw + j * 32 + li;
+        const bool live = q < ncols;
+        const int col = (live ? q : 0) * a.out_stride + phase;
+        const int row0 = i * 32 + 4 * lk;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = min(co0 + row0 + 8 * (r >> 2) + (r & 3), co_last);
+          rv[r] = has_res ? rb[co * a.lout + col] : 0.f;
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          float o4[4];
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb + row0 + 8 * r4);
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg + row0 + 8 * r4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = r4 * 4 + e;
+            const float v = finish(acc[i][j][r], NP == 2 ? acx[i][j][r] : 0.f, b4[e], g4[e], rv[r]);
+            const int co = co0 + row0 + 8 * r4 + e;
+            if (a.out && live && co <= co_last) ob[co * a.lout + col] = v;
+            o4[e] = v;
+          }
+          if (a.outp) {
+            const int co = co0 + row0 + 8 * r4;
+            if (live && co + 3 <= co_last) put_planes(o4, co, col);
+          }
+        }
+      }
+  }
+}
+
+// transposed conv, phase-tiled (conv_mfma_bf16_kernel<..., PH = true>): MT phases x 32 channels per work-group
+template <int MT, int G, int NP>
+static int launch_conv_bf16_ph(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
+  const ConvW& w = a.w;
+  constexpr int TT = 128, CO_T = MT * 32;
+  const int wx = (TT - 1) * a.x_stride + span;
+  const size_t smem = (size_t)(G * NP * wx + w.taps * G * NP * CO_T) * 32;
+  FMI_REQUIRE(smem <= 160 * 1024, "conv(bf16, phases): LDS tile of %zu bytes exceeds 160 KiB", smem);
+  FMI_REQUIRE(w.phases % MT == 0 && w.cout_pad % 32 == 0 && (w.cin_pad16 >> 4) % G == 0, "conv(bf16, phases): bad tiling");
+  dim3 grid(cdiv(ncols, TT), w.cout_pad / 32, a.B * (w.phases / MT)), block(256);
+  if (smem > 64 * 1024)
+    FMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_mfma_bf16_kernel<MT, 1, G, NP, 0, 0, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<MT, 1, G, NP, 0, 0, true>), grid, block, smem, s, a, ncols, wx, tap_off0);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
 }
 
 template <int MT, int NT, int G, int NP, int TAPS, int TC>
@@ -677,8 +760,35 @@ static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span
     for (int g : {8, 4, 2})   // both tiles of a step within 128 KiB of LDS
       if (g <= want && cgs % g == 0 && (size_t)g * NP * (4 * nt * 32 + MT * 32) * 32 <= 128 * 1024) { kg = g; break; }
   }
+  // transposed convs (two taps per phase): one 16-channel group per step is a chain of copy -> barrier -> 18 MFMAs ->
+  // barrier steps, C_in / 16 of them; 2 or 4 groups per step shorten the chain (bit-identical: group-major products)
+  static const int env_upg = []() { const char* e = getenv("FMI_CONV_UPG"); return e ? atoi(e) : 4; }();
+  // phase-tiled transposed convs (FMI_CONV_PH=0: one phase per work-group, A/B): 4 (stride 4, 8) or 2 phases per
+  // work-group; the output-column vector store needs lout rows 16-byte aligned per 4 columns
+  static const int env_ph = []() { const char* e = getenv("FMI_CONV_PH"); return e ? atoi(e) : 1; }();
+  if (env_ph && w.phases >= 2 && w.taps != 7 && a.out_stride == w.phases && w.cout_pad % 32 == 0 && a.lout % 4 == 0) {
+    const int cgs = w.cin_pad16 >> 4;
+    const int g = (env_ph >= 2 || cgs % 2) ? 1 : 2;
+    if (w.phases % 4 == 0) {
+      if (g == 2) return launch_conv_bf16_ph<4, 2, NP>(a, ncols, tap_off0, span, s);
+      return launch_conv_bf16_ph<4, 1, NP>(a, ncols, tap_off0, span, s);
+    }
+    if (w.phases % 2 == 0) {
+      if (g == 2) return launch_conv_bf16_ph<2, 2, NP>(a, ncols, tap_off0, span, s);
+      return launch_conv_bf16_ph<2, 1, NP>(a, ncols, tap_off0, span, s);
+    }
+  }
+  int ug = 1;
+  if (!k1 && w.taps > 1 && w.taps != 7 && NP == 2 && MT == 3) {
+    const int cgs = w.cin_pad16 >> 4;
+    const int wxu = 127 * a.x_stride + span;
+    for (int g : {4, 2})
+      if (g <= env_upg && cgs % g == 0 && (size_t)g * NP * (wxu + w.taps * MT * 32) * 32 <= 80 * 1024) { ug = g; break; }
+  }
 #define FMI_CONVB(MT_, NT_)                                                              \
   do {                                                                                   \
+    if (!k1 && ug == 4 && MT_ == 3 && NT_ == 1) return launch_conv_bf16_t<3, 1, 4, NP>(a, ncols, tap_off0, span, s); \
+    if (!k1 && ug == 2 && MT_ == 3 && NT_ == 1) return launch_conv_bf16_t<3, 1, 2, NP>(a, ncols, tap_off0, span, s); \
     if (!k1) return launch_conv_bf16_t<MT_, NT_, 1, NP>(a, ncols, tap_off0, span, s);    \
     if (kg == 8) return launch_conv_bf16_t<MT_, NT_, 8, NP>(a, ncols, tap_off0, span, s); \
     if (kg == 4) return launch_conv_bf16_t<MT_, NT_, 4, NP>(a, ncols, tap_off0, span, s); \
