@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
     }
     printf("M=%5d layer total:", M);
     int vi = 0;
-    for (const char* v = variants; *v; ++v, ++vi) printf("  %c %8.1f us (%.3f of 2.5 PF)", *v, total[vi], 2.0 * M * 101007360.0 / total[vi] * 1e-6 / 2.5e6);
+    for (const char* v = variants; *v; ++v, ++vi) printf("  %c %8.1f us (%.3f of 2.5 PF)", *v, total[vi], 2.0 * M * 101007360.0 / total[vi] * 1e-6 / 2.5e3);
     printf("\n");
   }
   return 0;

@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r03}
 shift || true
-SECTIONS=${*:-step codec prefill pmc attn stream}      # optional: only these sections
+SECTIONS=${*:-step codec prefill pmc attn stream gemm}      # optional: only these sections
 want() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
@@ -69,4 +69,8 @@ fi
 # timing-only runs (no profiler): streaming breakdown + latency
 want stream && python tools/stream_breakdown.py > "$OUT/${TAG}_stream_breakdown.txt" 2>&1
 want stream && python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt" 2>&1
+# prefill GEMM variants per shape (tools/gemm_bench.hip; the binary is built on the authoring side: see the file's header)
+if want gemm && [ -x tools/bin/gemm_bench ]; then
+{ echo "# tools/bin/gemm_bench lwx on MI355X (libfishmi.so sha1 $SHA, tree $HEAD): l = 4-wave LDS-staged, w = wave-specialised 128x128 (shipped), x = 128x256 three-stage tile"; tools/bin/gemm_bench lwx; } > "$OUT/${TAG}_gemm_bench.txt" 2>&1
+fi
 ls -la "$OUT"
