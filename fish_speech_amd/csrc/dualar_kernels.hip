@@ -802,7 +802,7 @@ __device__ inline u32x4 lds_read_b128(unsigned addr) {
   return v;
 }
 
-constexpr char FMI_GEMM_DEFAULT = 'w';   // prefill GEMM variant when FMI_GEMM is unset: wave-specialised (8 x 200 rows: 30.3 -> 25.4 ms, 8 x 2048: 225.9 -> 215.1 ms on MI355X; bit-identical)
+constexpr char FMI_GEMM_DEFAULT = 'a';   // 'a' = by shape: 'x' (128 x 256 tile) or 'w' (128 x 128), see launch_linear_tiled;   // prefill GEMM variant when FMI_GEMM is unset: wave-specialised (8 x 200 rows: 30.3 -> 25.4 ms, 8 x 2048: 225.9 -> 215.1 ms on MI355X; bit-identical)
 
 template <int EPI>
 __global__ __launch_bounds__(256) void linear_tiled_lds_kernel(LinearArgs a) {
@@ -1095,6 +1095,14 @@ int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, i
   // A/B switch: FMI_GEMM = d (operands straight from L2), l (LDS-staged, 4 waves), w (LDS-staged, wave-specialised)
   static const char env_mode = []() { const char* e = getenv("FMI_GEMM"); return e ? e[0] : '\0'; }();
   char mode = force_direct ? 'd' : variant == 1 ? 'l' : variant == 2 ? 'w' : variant == 3 ? 'x' : env_mode ? env_mode : FMI_GEMM_DEFAULT;
+  if (mode == 'a') {
+    // 128 x 256 tiles for the long prefills only.  In isolation the wide tile wins from ~160 work-groups on
+    // (profiles/r03_gemm_sweep.txt: 11 row counts x 4 shapes, e.g. 8 x 200 rows wqkv 96 vs 99 us, w1|w3 237 vs 259), but
+    // inside the layer sequence of a prefill that does not carry over below ~4 k rows: 8 x 200 tokens 26.0 vs 25.5 ms,
+    // 8 x 300 33.2 vs 32.0 with the rule "from 160 work-groups"; 8 x 1024 100.1 vs 101.3, 8 x 2048 204.8 vs 211.4.
+    // All variants give identical bits, so the choice may depend on the row count without touching batch invariance.
+    mode = (a.M >= 4096 && !(a.epi == EPI_SILU && a.M > 12288)) ? 'x' : 'w';
+  }
   if ((mode == 'w' || mode == 'x') && ((a.K >> 5) & 1)) mode = 'l';   // the wave-specialised loop takes k-tiles in pairs
   constexpr int smem = 2 * 32768;
   if (mode == 'x') {   // 128 x 256 tile, 8 compute + 4 loader waves, three 48 KiB stages

@@ -1,7 +1,7 @@
 // gemm_bench.hip -- the prefill GEMM variants (launch_linear_tiled: 'l' 4-wave LDS-staged, 'w' wave-specialised, 'x' the
 // 8-compute-wave 128 x 256 tile) on the S2-Pro prefill shapes, M = 8 x 200 and 8 x 2048 rows (round 3).
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFMI_WS_ABLATE=n] tools/gemm_bench.hip fish_speech_amd/csrc/common.cpp -o tools/bin/gemm_bench
-// Usage:  gemm_bench [variants, default lw] [shape name] [M]
+// Usage:  [GEMM_MS=m1,m2,...] gemm_bench [variants, default lw] [shape name] [M]
 //   FMI_WS_ABLATE (resource ablation of the 'w' kernel, results are garbage): 1 = the loader waves issue only the first
 //   two stages (no DMA in the steady state), 2 = no MFMA (operand reads only), 3 = no operand reads (MFMA on stale registers)
 // Every variant is checked bit for bit against 'l' (same products, same order) and timed over NBUF weight copies.
@@ -69,7 +69,11 @@ static void mfma_peak() {
 int main(int argc, char** argv) {
   mfma_peak();
   const Shape shapes[] = {{"wqkv", 6144, 2560, EPI_STORE}, {"wo", 2560, 4096, EPI_RESIDUAL}, {"w1|w3", 19456, 2560, EPI_SILU}, {"w2", 2560, 9728, EPI_RESIDUAL}};
-  const int Ms[] = {1600, 16384};
+  std::vector<int> Ms = {1600, 16384};
+  if (getenv("GEMM_MS")) {      // e.g. GEMM_MS=200,400,800 : sweep of row counts
+    Ms.clear();
+    for (const char* p = getenv("GEMM_MS"); *p;) { Ms.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+  }
   const char* variants = argc > 1 ? argv[1] : "lw";
   const char* only_shape = argc > 2 ? argv[2] : "";      // e.g. "w2"; "" = all
   const int only_m = argc > 3 ? atoi(argv[3]) : 0;       // 0 = both row counts
