@@ -163,3 +163,54 @@ def test_extract_vq_sharding_and_cli_surface(tmp_path, monkeypatch):
     assert res.exit_code == 0
     for flag in ("--num-workers", "--config-name", "--checkpoint-path", "--batch-size", "--filelist", "FOLDER"):
         assert flag in res.output
+
+
+def test_third_party_dac_restatement_agrees_with_the_transformers_port():
+    """The codec imports `dac.nn.quantize` / `dac.nn.layers` from descript-audio-codec, a wheel that
+    is not in this image; oracle/stubs/dac restates them.  HF transformers ships an independent port of the same
+    package (`transformers.models.dac.modeling_dac`), so the restatement is checked against it with shared weights:
+    Snake1d bit for bit, `ResidualVectorQuantize.from_codes` bit for bit, the whole residual quantisation loop
+    (in_proj -> nearest normalised code -> out_proj -> subtract) with equal codes and bit-equal sums.  The port writes
+    the distance as -(|e|^2 - 2 e.c) + |c|^2 where the package has -(|e|^2 - 2 e.c + |c|^2): |c|^2 is 1 up to rounding
+    for the l2-normalised codebook, so the argmax can only differ on near-ties -- none on this input."""
+    import sys
+
+    import pytest as _pytest
+
+    modeling = _pytest.importorskip("transformers.models.dac.modeling_dac")
+    from transformers.models.dac.configuration_dac import DacConfig
+
+    from oracle.refload import STUBS
+
+    if STUBS not in sys.path:
+        sys.path.insert(0, STUBS)
+    from dac.nn.layers import Snake1d
+    from dac.nn.quantize import ResidualVectorQuantize
+
+    torch.manual_seed(0)
+    # Snake1d (dac/nn/layers.py): x + sin^2(alpha x) / (alpha + 1e-9)
+    mine, theirs = Snake1d(24), modeling.Snake1d(24)
+    with torch.no_grad():
+        mine.alpha.copy_(torch.rand(1, 24, 1) * 3 + 0.05)
+        theirs.alpha.copy_(mine.alpha)
+    x = torch.randn(2, 24, 77) * 2
+    assert torch.equal(mine(x), theirs(x))
+
+    D, NCB, CBS, CD = 48, 4, 256, 8
+    rvq = ResidualVectorQuantize(input_dim=D, n_codebooks=NCB, codebook_size=CBS, codebook_dim=CD).eval()
+    cfg = DacConfig(hidden_size=D, n_codebooks=NCB, codebook_size=CBS, codebook_dim=CD, quantizer_dropout=0.0)
+    port = modeling.DacResidualVectorQuantizer(cfg).eval()
+    z = torch.randn(2, D, 61)
+    with torch.no_grad():
+        rvq(z)                                   # materialises the weight-normed convs' effective weights
+        for q, p in zip(rvq.quantizers, port.quantizers):
+            p.in_proj.weight.copy_(q.in_proj.weight); p.in_proj.bias.copy_(q.in_proj.bias)
+            p.out_proj.weight.copy_(q.out_proj.weight); p.out_proj.bias.copy_(q.out_proj.bias)
+            p.codebook.weight.copy_(q.codebook.weight)
+        zq, codes, latents, _, _ = rvq(z)
+        pq, pcodes, platents, _, _ = port(z)
+        assert torch.equal(codes, pcodes) and codes.shape == (2, NCB, 61)
+        assert torch.equal(latents, platents) and torch.equal(zq, pq)
+        a, b, c = rvq.from_codes(codes)
+        pa, pb, pc = port.from_codes(codes)
+        assert torch.equal(a, pa) and torch.equal(b, pb) and torch.equal(c, pc)
