@@ -428,7 +428,8 @@ def run_config5_staggered(model, codec, cfg, n_req=16, gap_s=0.25):
     utterance streamed on its own chunk schedule, slots refilled as utterances finish.  Reports first-audio latency
     from arrival (p50 / p90 over the requests, queueing for a slot included) and whole-run throughput.  gap_s = 0.25:
     40 audio-seconds demanded per second, about 0.8 of what this loop sustains (at 0.12 s the queue grows without
-    bound and the latency is queueing time: p50 194 ms, p90 399 ms measured)."""
+    bound and the latency is queueing time: p50 194 ms, p90 399 ms measured).  serve_stream cuts an advance short when
+    a request is about to arrive and a slot is free (admit_early): 81 / 92 -> 61 / 65 ms p50 / p90 at this load."""
     import statistics
 
     from fish_speech_amd.serving import StreamRequest, serve_stream

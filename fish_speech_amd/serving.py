@@ -64,9 +64,13 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
                  step_frames: int = 8, first_chunk_frames: int = 8, chunk_frames: int = 32, chunk_growth: float = 2.0,
                  max_chunk_frames: int = 256, temperature: float = 1.0, top_p: float = 0.9, top_k: int = 30,
                  use_ras: bool = True, clock: Callable[[], float] = time.perf_counter,
-                 wait: Callable[[float], None] = time.sleep) -> Iterator[StreamEvent]:
+                 wait: Callable[[float], None] = time.sleep, admit_early: bool = True) -> Iterator[StreamEvent]:
     """Serve `requests` (any iterable, consumed lazily in order) through `max_batch` slots; yields StreamEvents as
-    audio becomes available.  A request is admitted once `clock() - start >= request.arrival` and a slot is free."""
+    audio becomes available.  A request is admitted once `clock() - start >= request.arrival` and a slot is free.
+    `admit_early`: while a slot is free and the next request is known but not yet due, the advance is cut short so
+    that it ends about when the request arrives (frame time measured on the fly) -- a new utterance then waits for
+    the rest of ONE frame instead of the rest of a `step_frames` advance; nothing about any utterance's audio
+    depends on how the advances are cut."""
     cfg = model.config
     if not model._cache_setup_done:
         model.setup_caches(max_batch_size=max_batch or 8, max_seq_len=cfg.max_seq_len)
@@ -80,6 +84,7 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
     live: dict = {}
     start = clock()
     fl = codec.frame_length
+    frame_s = 0.0                            # measured wall time per decode frame (moving average)
 
     def next_request():
         nonlocal pending, exhausted
@@ -114,9 +119,16 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
         # ---- advance every live utterance
         slots = sorted(live)
         need = min(step_frames, max(u.limit - u.generated for u in live.values()))
+        if admit_early and need > 1 and free and frame_s > 0.0 and next_request() is not None:
+            until = pending.arrival - (clock() - start)          # > 0: the admission loop above did not take it
+            need = max(1, min(need, int(until / frame_s) + 1))
+        t_adv = clock()
         if need > 0:
             model.decode(slots, need)
         done = model.poll_done(slots)
+        if need > 0:
+            dt = (clock() - t_adv) / need
+            frame_s = dt if frame_s == 0.0 else 0.8 * frame_s + 0.2 * dt
         for s, d in zip(slots, done):
             u = live[s]
             u.generated = min(u.limit, u.generated + need)

@@ -169,6 +169,45 @@ def test_generate_stream_emits_exactly_the_offline_frames(first, chunk, growth):
         assert b[1] == a[0]
 
 
+def test_serve_stream_cuts_an_advance_short_for_a_request_about_to_arrive():
+    """admit_early: with a free slot and the next request known but not yet due, the advance ends about when it
+    arrives (measured frame time), so it is prefilled at most one frame late instead of up to a whole advance."""
+    from fish_speech_amd.serving import StreamRequest, serve_stream
+
+    def run(early):
+        model, codec = StubDualAR(max_batch=3), StubCodec()
+        now = [0.0]
+        calls = []
+        orig_decode, orig_prefill = model.decode, model.prefill
+
+        def decode(slots, n):
+            now[0] += 0.010 * n                       # 10 ms of fake time per frame
+            calls.append(("decode", n, round(now[0], 3)))
+            return orig_decode(slots, n)
+
+        def prefill(slots, *a, **k):
+            calls.append(("prefill", len(slots), round(now[0], 3)))
+            return orig_prefill(slots, *a, **k)
+
+        model.decode, model.prefill = decode, prefill
+        reqs = [StreamRequest(prompt=torch.zeros(NCB + 1, 5, dtype=torch.int64), seed=11, rid=0, arrival=0.0),   # 35 frames
+                StreamRequest(prompt=torch.zeros(NCB + 1, 6, dtype=torch.int64), seed=8, rid=1, arrival=0.205)]
+        evs = list(serve_stream(model=model, codec=codec, requests=iter(reqs), max_batch=3, step_frames=8,
+                                clock=lambda: now[0], wait=lambda dt: now.__setitem__(0, now[0] + dt), admit_early=early))
+        second = [c for c in calls if c[0] == "prefill"][1]
+        return second[2] - 0.205, calls, evs
+
+    late_fixed, _, ev0 = run(False)
+    late_early, calls, ev1 = run(True)
+    assert late_fixed > 0.02 and 0.0 <= late_early <= 0.0101, (late_fixed, late_early)
+    assert any(c[0] == "decode" and c[1] < 8 for c in calls)
+    # the audio does not depend on how the advances are cut
+    a = {(e.rid, e.t0): e for e in ev0 if e.kind == "segment"}
+    cat = lambda evs, rid: torch.cat([e.codes for e in evs if e.kind == "segment" and e.rid == rid], dim=1)
+    for rid in (0, 1):
+        assert torch.equal(cat(ev0, rid), cat(ev1, rid))
+
+
 @pytest.mark.parametrize("step,first,chunk,growth", [(8, 8, 32, 2.0), (1, 1, 1, 1.0), (5, 3, 4, 1.5), (16, 2, 64, 1.0)])
 def test_serve_stream_refills_slots_and_every_utterance_equals_its_offline_result(step, first, chunk, growth):
     """serving.serve_stream = continuous batching + per-utterance chunk schedules: 9 requests (natural lengths 4..40
