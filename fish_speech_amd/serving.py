@@ -12,7 +12,7 @@ Mechanics: all live slots advance together by `step_frames` frames per `MiDualAR
 per frame); after each advance the loop decodes, for every utterance whose schedule is due, the frames it has not
 voiced yet with `MiDAC.from_indices_tail(stream_id=...)` -- the codec keeps one quantizer-side state per open stream
 (csrc/dac.hip: select_stream_state).  Like `generate_long` (inference.py:708) the last generated frame of an
-utterance is never voiced."""
+utterance is never voiced (see stream.py for why a live utterance's newest frame can be)."""
 from __future__ import annotations
 
 import time
@@ -104,7 +104,7 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
             if T >= cfg.max_seq_len:  # inference.py:263-266
                 raise ValueError(f"Input sequence length {T} exceeds max_seq_len {cfg.max_seq_len}")
             limit = min(r.max_new_tokens if r.max_new_tokens else cfg.max_seq_len - T, cfg.max_seq_len - T)
-            marks = chunk_schedule(limit, first_chunk_frames + 1, chunk_frames, chunk_growth, max_chunk_frames)
+            marks = chunk_schedule(limit, first_chunk_frames, chunk_frames, chunk_growth, max_chunk_frames)
             new.append(_Live(r, free.pop(), limit, marks, stream_id=codec.new_stream_id()))
         if new:
             samp = [model._sampling(temperature, top_p, top_k, u.req.seed if u.req.seed is not None else model.next_seed(),
@@ -134,12 +134,13 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
             u.generated = min(u.limit, u.generated + need)
             if u.length is None and (d or u.generated >= u.limit):
                 u.length = model.read(s)[0].shape[0] if d else u.limit
-        # ---- voice what is due: the newest frame of a live utterance is held back, the last one never voiced
+        # ---- voice what is due: the last frame of an utterance is never voiced; a live utterance (the poll above says
+        # it has not ended and its budget is not used up) will get another frame, so its newest one is voiceable
         for s in slots:
             u = live[s]
             ended = u.length is not None
-            voiced = (u.length if ended else u.generated) - 1
-            due = ended or any(u.emitted < m - 1 <= voiced for m in u.marks)
+            voiced = u.length - 1 if ended else u.generated
+            due = ended or any(u.emitted < m <= voiced for m in u.marks)
             if due and voiced > u.emitted:
                 frames = model.frames_device(model.max_batch_size, voiced)[s]          # (voiced, 1+ncb) int32
                 codes = frames[:, 1:].t().to(torch.int64).contiguous()                  # (ncb, voiced)

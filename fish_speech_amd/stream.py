@@ -16,8 +16,10 @@ granularity.  What is emitted is exactly what the offline path produces:
   is bit-identical to ``from_indices`` over the final codes (tests/test_stream_gpu.py).
 
 Like ``generate_long`` (inference.py:708, ``codes = y[1:, T:-1]``) the last generated frame of an
-utterance -- the ``<|im_end|>`` frame, or the one that hit ``max_new_tokens`` -- is never voiced, so the
-stream holds the newest frame back until a later one exists.
+utterance -- the ``<|im_end|>`` frame, or the one that hit ``max_new_tokens`` -- is never voiced.  A live utterance's
+newest frame is known not to be that frame as soon as the poll after it says "not ended" and the frame budget is not
+used up (another frame WILL follow), so it is voiced right away: the first chunk leaves after ``first_chunk_frames``
+generated frames, not one later.
 """
 from __future__ import annotations
 
@@ -98,7 +100,7 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
     stream_id = codec.new_stream_id()                  # the codec keeps its quantizer-side state between our calls
     length = [None] * n                                # final frame count of an utterance once it ended
     try:
-        for mark in chunk_schedule(total, first_chunk_frames + 1, chunk_frames, chunk_growth, max_chunk_frames):
+        for mark in chunk_schedule(total, first_chunk_frames, chunk_frames, chunk_growth, max_chunk_frames):
             tm = [time.perf_counter()] if timing is not None else None
             if mark > generated:
                 model.decode(slots, mark - generated)
@@ -110,8 +112,9 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
                 if length[i] is None and (done[i] or generated >= mn[i]):
                     length[i] = model.read(i)[0].shape[0] if done[i] else mn[i]
             finished = [length[i] is not None for i in slots]
-            # voiced frames of utterance i: [0, length-1); the newest frame of a live utterance is held back
-            voiced = [(length[i] if finished[i] else generated) - 1 for i in slots]
+            # voiced frames of utterance i: [0, length-1) once it ended; a live one (not ended by the poll above, budget
+            # not used up) will get another frame, so all of its frames so far are voiceable
+            voiced = [length[i] - 1 if finished[i] else generated for i in slots]
             t1 = max(voiced)
             if t1 > emitted:
                 frames = model.frames_device(n, t1)                       # (B, t1, 1+ncb) int32
