@@ -429,7 +429,7 @@ def run_config5_staggered(model, codec, cfg, n_req=16, gap_s=0.25):
     from arrival (p50 / p90 over the requests, queueing for a slot included) and whole-run throughput.  gap_s = 0.25:
     40 audio-seconds demanded per second, about 0.8 of what this loop sustains (at 0.12 s the queue grows without
     bound and the latency is queueing time: p50 194 ms, p90 399 ms measured).  serve_stream cuts an advance short when
-    a request is about to arrive and a slot is free (admit_early): 81 / 92 -> 61 / 65 ms p50 / p90 at this load."""
+    a request is about to arrive and a slot is free (admit_early): 81 / 92 -> 55 / 62 ms p50 / p90 at this load together with voicing the newest frame at once."""
     import statistics
 
     from fish_speech_amd.serving import StreamRequest, serve_stream

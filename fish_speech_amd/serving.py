@@ -119,6 +119,10 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
         # ---- advance every live utterance
         slots = sorted(live)
         need = min(step_frames, max(u.limit - u.generated for u in live.values()))
+        # an utterance that has not been heard yet: stop the advance at its first mark, not up to step_frames - 1 later
+        for u in live.values():
+            if not u.first_done and u.marks and u.marks[0] > u.generated:
+                need = max(1, min(need, u.marks[0] - u.generated))
         if admit_early and need > 1 and free and frame_s > 0.0 and next_request() is not None:
             until = pending.arrival - (clock() - start)          # > 0: the admission loop above did not take it
             need = max(1, min(need, int(until / frame_s) + 1))
