@@ -143,6 +143,134 @@ class StreamingTTSEngine(ReferenceLoader, VQManager):
                 pass
 
 
+class BatchingTTSEngine(StreamingTTSEngine):
+    """The same `inference()` protocol, but concurrent callers SHARE the GPU: every request thread's utterances go
+    through one `serving.serve_stream` loop (continuous batching, up to `max_batch` utterances advance per pass over the
+    weights, each streamed on its own chunk schedule) instead of taking turns behind the model's lock.  The reference
+    serves one request at a time (its single-worker llama queue, text2semantic/inference.py:748-799); a request's
+    audio here is still exactly what it would be alone -- the kernels are batch-invariant (tests/test_stream_gpu.py).
+
+    One daemon thread runs the loop while there is work and holds `model.lock` only then, so other users of the
+    model get it between bursts.  Text chunks of one request are generated one after the other (each chunk's prompt
+    contains the previous chunk's codes); prefix-KV reuse across chunks is not used on this path."""
+
+    def __init__(self, model, codec, precision=torch.bfloat16, max_batch: int = 8, step_frames: int = 8,
+                 result_timeout: float = 600.0):
+        super().__init__(model, codec, precision)
+        import itertools
+        import threading
+
+        from .serving import RequestFeed
+
+        self.max_batch, self.step_frames, self.result_timeout = max_batch, step_frames, result_timeout
+        self._feed = RequestFeed()
+        self._queues: dict = {}
+        self._rid = itertools.count()
+        self._mutex = threading.Lock()
+        self._thread = None
+
+    # ---- the serving thread
+    def _ensure_thread(self):
+        import threading
+
+        with self._mutex:
+            if self._thread is None or not self._thread.is_alive():
+                self._thread = threading.Thread(target=self._serve, name="fishmi-serve", daemon=True)
+                self._thread.start()
+
+    def _serve(self):
+        from .serving import serve_stream
+
+        model, codec = self.model, self.decoder_model
+        while not self._feed.closed:
+            if not self._feed.wait(1.0):
+                continue
+            try:
+                with getattr(model, "lock", None) or contextlib.nullcontext(), torch.no_grad(), \
+                        torch.autocast("cuda", dtype=self.precision, enabled=self.precision is not None):
+                    for ev in serve_stream(model=model, codec=codec, requests=self._feed, max_batch=self.max_batch,
+                                           step_frames=self.step_frames, return_when_idle=True):
+                        q = self._queues.get(ev.rid)
+                        if q is not None:
+                            q.put(ev)
+            except Exception as e:   # noqa: BLE001 -- every waiting request gets the error instead of a hang
+                for q in list(self._queues.values()):
+                    q.put(e)
+
+    def close(self):
+        self._feed.close()
+
+    # ---- one utterance through the shared loop
+    def _stream_utterance(self, prompt, req: TTSRequest, seed):
+        import queue
+
+        from .serving import StreamRequest
+
+        rid = next(self._rid)
+        q: "queue.Queue" = queue.Queue()
+        self._queues[rid] = q
+        sreq = StreamRequest(prompt=prompt, max_new_tokens=req.max_new_tokens, seed=seed, rid=rid,
+                             temperature=req.temperature, top_p=req.top_p, top_k=req.top_k,
+                             first_chunk_frames=req.first_chunk_frames, chunk_frames=req.chunk_frames,
+                             chunk_growth=req.chunk_growth, max_chunk_frames=req.max_chunk_frames)
+        try:
+            self._feed.put(sreq)
+            self._ensure_thread()
+            while True:
+                ev = q.get(timeout=self.result_timeout)
+                if isinstance(ev, Exception):
+                    raise ev
+                if ev.kind == "final":
+                    return
+                yield ev
+        finally:
+            sreq.cancelled = True            # no-op once it ended; frees the slot if the consumer went away early
+            self._queues.pop(rid, None)
+
+    @torch.no_grad()
+    def inference(self, req: TTSRequest) -> Iterator[InferenceResult]:
+        model, codec = self.model, self.decoder_model
+        sample_rate = codec.sample_rate
+        try:
+            if req.streaming:
+                yield InferenceResult("header", (sample_rate, np.array(wav_chunk_header(sample_rate=sample_rate))), None)
+            prompt_tokens, prompt_texts = list(req.prompt_tokens), list(req.prompt_texts)
+            if req.reference_id is not None:
+                prompt_tokens, prompt_texts = self.load_by_id(req.reference_id, req.use_memory_cache)
+            elif req.references:
+                prompt_tokens, prompt_texts = self.load_by_hash(list(req.references), req.use_memory_cache)
+            use_prompt = bool(prompt_texts) and bool(prompt_tokens)
+            system = _system_message(list(prompt_texts) if use_prompt else None,
+                                     [c.cpu() for c in prompt_tokens] if use_prompt else None)
+            turns = split_text_by_speaker(req.text)
+            chunks = group_turns_into_batches(turns, max_speakers=5, max_bytes=req.chunk_length) if turns else [req.text]
+            history = Conversation([system])
+            segments: List[np.ndarray] = []
+            for ci, chunk in enumerate(chunks):
+                history.append(Message(role="user", parts=[TextPart(text=chunk)]))
+                asking = history.copy()
+                asking.append(Message(role="assistant", parts=[], modality="voice", add_im_end=False))
+                prompt, _, _ = asking.encode_for_inference(model.tokenizer, num_codebooks=model.config.num_codebooks)
+                if prompt.size(1) > model.config.max_seq_len - 2048:    # text2semantic/inference.py:658-661
+                    raise ValueError(f"Prompt is too long: {prompt.size(1)} > {model.config.max_seq_len - 2048}")
+                codes_parts = []
+                for ev in self._stream_utterance(prompt, req, None if req.seed is None else int(req.seed) + ci):
+                    seg = ev.audio[0, 0].float().cpu().numpy()
+                    codes_parts.append(ev.codes.cpu())
+                    segments.append(seg)
+                    if req.streaming:
+                        yield InferenceResult("segment", (sample_rate, seg), None)
+                if codes_parts:
+                    history.append(Message(role="assistant", parts=[VQPart(codes=torch.cat(codes_parts, dim=1))],
+                                           modality="voice"))
+            if not segments:
+                yield InferenceResult("error", None, RuntimeError("No audio generated, please check the input text."))
+            else:
+                yield InferenceResult("final", (sample_rate, np.concatenate(segments, axis=0)), None)
+        except Exception as e:   # the reference reports worker errors as a result, not as a raise (__init__.py:88-98)
+            yield InferenceResult("error", None, e)
+
+
 def inference_wrapper(req: TTSRequest, engine: StreamingTTSEngine):
     """tools/server/inference.py:12-45: the byte stream the HTTP endpoint sends."""
     count = 0

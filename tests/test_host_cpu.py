@@ -5,6 +5,7 @@ the server's batch codec helpers (tools/server/model_utils.py:15-86).  The stand
 codec API those modules call; the GPU runs of the same code are in tests/test_stream_gpu.py."""
 import io
 import itertools
+import time
 import wave
 from types import SimpleNamespace
 
@@ -358,6 +359,69 @@ def test_engine_protocol_and_byte_stream():
     pcm = b"".join(chunks[1:-1])
     assert pcm == (want * 32768).astype(np.int16).tobytes()
     assert np.array_equal(chunks[-1], want)
+
+
+@pytest.mark.timeout(60)
+def test_batching_engine_serves_concurrent_requests_through_one_loop():
+    """BatchingTTSEngine: request threads share one serve_stream loop (continuous batching) instead of taking turns;
+    every request's result equals the serial engine's, the protocol is unchanged, several utterances were in flight
+    together, an abandoned request frees its slot, errors come back as results, and the loop lets go of the model's
+    lock between bursts."""
+    import threading
+
+    from fish_speech_amd.engine import BatchingTTSEngine
+
+    codec = StubCodec()
+    serial = StreamingTTSEngine(StubDualAR(max_batch=1), codec, precision=None)
+    model = StubDualAR(max_batch=4)
+    model.lock = threading.RLock()
+    peak = [0]
+    orig_decode = model.decode
+
+    def decode(slots, n):
+        peak[0] = max(peak[0], len(slots))
+        time.sleep(0.002)                     # give the other request threads time to arrive while this one is live
+        return orig_decode(slots, n)
+
+    model.decode = decode
+    eng = BatchingTTSEngine(model, codec, precision=None, max_batch=4, step_frames=4)
+    reqs = [TTSRequest(text=f"hello there {i}", streaming=bool(i % 2), max_new_tokens=64, seed=2 + i, first_chunk_frames=2,
+                       chunk_frames=3) for i in range(6)]
+    want = [list(serial.inference(r)) for r in reqs]
+    got = [None] * len(reqs)
+
+    def run(i):
+        got[i] = list(eng.inference(reqs[i]))
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(len(reqs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(30)
+    assert all(g is not None for g in got) and peak[0] >= 2
+    for r, g, w in zip(reqs, got, want):
+        assert g[-1].code == "final" and np.array_equal(g[-1].audio[1], w[-1].audio[1])
+        assert [x.code for x in g][:1] == (["header"] if r.streaming else ["final"])
+        if r.streaming:
+            assert np.array_equal(np.concatenate([x.audio[1] for x in g[1:-1]]), g[-1].audio[1])
+    time.sleep(0.1)
+    assert not model.slots and model.lock.acquire(blocking=False)      # idle: nothing held
+    model.lock.release()
+    # a consumer that walks away after the first segment: its utterance is cancelled and the slot comes back
+    gen = eng.inference(TTSRequest(text="a long one", streaming=True, max_new_tokens=64, seed=11, first_chunk_frames=1, chunk_frames=1))
+    assert next(gen).code == "header" and next(gen).code == "segment"
+    gen.close()
+    for _ in range(200):
+        if not model.slots:
+            break
+        time.sleep(0.01)
+    assert not model.slots
+    # errors are results, and the loop survives them
+    res = list(eng.inference(TTSRequest(text="hi", max_new_tokens=1, seed=1)))
+    assert [r.code for r in res] == ["error"] and "No audio generated" in str(res[0].error)
+    again = list(eng.inference(reqs[0]))
+    assert np.array_equal(again[-1].audio[1], want[0][-1].audio[1])
+    eng.close()
 
 
 def test_engine_reports_errors_as_results():

@@ -1,6 +1,8 @@
 """Streaming chunked decode (BASELINE.json config 5) on the GPU: what is streamed must be exactly what
 the offline path produces -- codes from ``generate_batch``, audio from ``MiDAC.from_indices`` over the
 final codes (``codes = y[1:, T:-1]``, inference.py:708) -- for any chunking."""
+import time
+
 import pytest
 import torch
 
@@ -563,3 +565,76 @@ def test_engine_streaming_segments_equal_final_equal_offline():
     for i in range(4):
         assert np.array_equal(got[i], want_audio[i]), i
 
+
+
+@pytest.mark.timeout(240)
+def test_batching_engine_concurrent_requests_equal_their_serial_results():
+    """engine.BatchingTTSEngine: four request threads at once (two text chunks each, streaming and not) share ONE
+    serve_stream loop -- several utterances advance per pass over the weights -- and every thread gets, bit for bit,
+    the audio the serial StreamingTTSEngine produces for its request; the slots and the model's lock are free
+    afterwards."""
+    import threading
+
+    import numpy as np
+
+    from fish_speech_amd.dac import DacConfig, MiDAC
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR
+    from fish_speech_amd.engine import BatchingTTSEngine, StreamingTTSEngine, TTSRequest
+    from oracle import dual_ar as O
+    from oracle.fake_tokenizer import ByteTokenizer
+
+    tok = ByteTokenizer()
+    cfg = O.DualARConfig(vocab_size=tok.vocab_size + 4, dim=128, n_layer=2, n_head=4, n_local_heads=2, head_dim=32,
+                         intermediate_size=256, max_seq_len=2048 + 512, codebook_size=4096, num_codebooks=10,
+                         semantic_begin_id=tok.semantic_begin_id, semantic_end_id=tok.semantic_end_id,
+                         im_end_id=tok.get_token_id("<|im_end|>"), n_fast_layer=2)
+    model = MiDualAR.from_state_dict(DualARConfig.from_any(cfg), O.make_synthetic_state(cfg, seed=5, head_gain=4.0),
+                                     device=DEV, im_end_id=cfg.im_end_id)
+    model.tokenizer = tok
+    model.setup_caches(4, cfg.max_seq_len)
+    ccfg = D.DacConfig(encoder_dim=8, decoder_dim=96, n_codebooks=9, codebook_size=1024, semantic_codebook_size=4096,
+                       tf_layers=2, tf_window=8, enc_tf_layers=2, enc_tf_window=16)
+    codec = MiDAC.from_state_dict(DacConfig.from_any(ccfg), D.make_synthetic_state(ccfg, seed=2), device=DEV)
+    text = "<|speaker:0|>First chunk of text.<|speaker:1|>Second chunk, another speaker."
+    reqs = [TTSRequest(text=text, max_new_tokens=21 + 3 * i, chunk_length=30, seed=70 + i, first_chunk_frames=3, chunk_frames=5,
+                       streaming=bool(i % 2)) for i in range(4)]
+    serial = StreamingTTSEngine(model, codec)
+    want = [[r for r in serial.inference(q)] for q in reqs]
+    assert all(w[-1].code == "final" for w in want)
+
+    eng = BatchingTTSEngine(model, codec, max_batch=4, step_frames=4)
+    in_flight = [0]
+    orig_decode = model.decode
+
+    def decode(slots, n):
+        in_flight[0] = max(in_flight[0], len(slots))
+        return orig_decode(slots, n)
+
+    model.decode = decode
+    got, errs = [None] * 4, []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            got[i] = [r for r in eng.inference(reqs[i])]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs and all(g is not None for g in got), errs
+    assert in_flight[0] >= 2                  # they really shared passes over the weights
+    for q, g, w in zip(reqs, got, want):
+        assert g[-1].code == "final" and np.array_equal(g[-1].audio[1], w[-1].audio[1])
+        if q.streaming:
+            assert g[0].code == "header"
+            assert np.array_equal(np.concatenate([r.audio[1] for r in g if r.code == "segment"]), g[-1].audio[1])
+    time.sleep(0.2)
+    assert model.lock.acquire(blocking=False)
+    model.lock.release()
+    # the serial engine still works on the same model afterwards (slots were released)
+    assert np.array_equal([r for r in serial.inference(reqs[0])][-1].audio[1], want[0][-1].audio[1])
+    eng.close()
