@@ -362,6 +362,48 @@ def test_engine_protocol_and_byte_stream():
 
 
 @pytest.mark.timeout(60)
+def test_serve_stream_over_a_request_feed_per_request_parameters_and_cancellation():
+    """serve_stream fed by a RequestFeed (requests appear while the loop runs): per-request sampling parameters and chunk
+    schedule override the loop's, a cancelled utterance leaves at the next poll and its slot is reused, the loop
+    returns when idle if asked to, and a closed feed ends a waiting loop."""
+    import threading
+
+    from fish_speech_amd.serving import RequestFeed, StreamRequest, collect, serve_stream
+
+    model, codec = StubDualAR(max_batch=2), StubCodec()
+    seen = []
+    orig = model._sampling
+    model._sampling = lambda t, p, k, seed, ras: (seen.append((t, p, k)), orig(t, p, k, seed, ras))[1]
+    feed = RequestFeed()
+    a = StreamRequest(prompt=torch.zeros(NCB + 1, 5, dtype=torch.int64), seed=11, rid=1, temperature=0.3, top_k=5,
+                      first_chunk_frames=2, chunk_frames=2)
+    b = StreamRequest(prompt=torch.zeros(NCB + 1, 6, dtype=torch.int64), seed=8, rid=2)
+    c = StreamRequest(prompt=torch.zeros(NCB + 1, 7, dtype=torch.int64), seed=5, rid=3)
+    feed.put(a); feed.put(b); feed.put(c)                       # c waits for a slot
+    assert len(feed) == 3 and a.arrival_abs is not None
+    evs = []
+    for ev in serve_stream(model=model, codec=codec, requests=feed, max_batch=2, step_frames=4, first_chunk_frames=8,
+                           chunk_frames=32, temperature=0.9, top_p=0.8, top_k=30, return_when_idle=True):
+        evs.append(ev)
+        if ev.rid == 2 and ev.kind == "segment":
+            b.cancelled = True                                  # the consumer of utterance 2 goes away
+    got = collect(evs, codec.frame_length)
+    assert (0.3, 0.8, 5) in seen and (0.9, 0.8, 30) in seen    # request a's overrides, the loop's defaults for b / c
+    assert torch.equal(got[1][1], model.expected_codes(11, 10 ** 6)) and torch.equal(got[3][1], model.expected_codes(5, 10 ** 6))
+    assert got[2][1].shape[1] < model.expected_codes(8, 10 ** 6).shape[1]          # cut short, yet a final was sent
+    assert sorted(e.rid for e in evs if e.kind == "final") == [1, 2, 3] and not model.slots
+    segs_a = [e for e in evs if e.rid == 1 and e.kind == "segment"]
+    assert segs_a[0].t1 == 2 and len(segs_a) >= 4                                  # its own 2-frame schedule
+    # a loop that waits on an empty feed ends when the feed is closed
+    feed2 = RequestFeed()
+    t = threading.Timer(0.2, feed2.close)
+    t.start()
+    assert list(serve_stream(model=model, codec=codec, requests=feed2, max_batch=2)) == []
+    with pytest.raises(RuntimeError):
+        feed2.put(a)
+
+
+@pytest.mark.timeout(60)
 def test_batching_engine_serves_concurrent_requests_through_one_loop():
     """BatchingTTSEngine: request threads share one serve_stream loop (continuous batching) instead of taking turns;
     every request's result equals the serial engine's, the protocol is unchanged, several utterances were in flight
