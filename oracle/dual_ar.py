@@ -432,6 +432,61 @@ def quantize_state_int8(cfg: "DualARConfig", state: Dict[str, torch.Tensor]) -> 
     return out
 
 
+# --- int4 group-wise weight-only quantisation (tools/llama/quantize.py:52-163,300-349): GROUNDWORK ONLY.
+# What is restated and pinned here (tests/test_oracle_cpu.py, against the unmodified reference functions): the group
+# parameters, the 4-bit values, the packed scales_and_zeros tensor and the handler's padding of in_features to a
+# multiple of 1024.  What is NOT, and why the product path refuses int4: `_convert_weight_to_int4pack` (the CUDA-only
+# tile shuffle of the 4-bit values; the handler calls it on "cuda") and `_weight_int4pack_mm`'s arithmetic cannot be
+# run, hence not pinned, in this container.
+
+
+def int4_group_qparams(w: torch.Tensor, groupsize: int = 128):
+    """get_group_qparams (quantize.py:52-74) for n_bit = 4: per (row, group of `groupsize` columns)
+    scale = (max - min).clamp(1e-6) / 15, zero = min + 8 * scale, both rounded to bf16."""
+    assert w.dim() == 2 and w.shape[-1] % groupsize == 0
+    g = w.reshape(-1, groupsize)
+    mx, mn = g.amax(dim=1, keepdim=True), g.amin(dim=1, keepdim=True)
+    scales = (mx - mn).clamp(min=1e-6) / 15
+    zeros = mn + scales * 8
+    return scales.to(torch.bfloat16).reshape(w.shape[0], -1), zeros.to(torch.bfloat16).reshape(w.shape[0], -1)
+
+
+def quantize_int4_groups(w: torch.Tensor, groupsize: int = 128):
+    """group_quantize_tensor (quantize.py:96-125): 4-bit values (int32, 0..15) [N][K] and scales_and_zeros
+    [K / groupsize][N][2] bf16.  The values are computed FROM the bf16-rounded parameters: q = round((w - min') / scale)
+    with min' = zero - 8 * scale, clamped to [0, 15]."""
+    scales, zeros = int4_group_qparams(w, groupsize)
+    g = w.reshape(-1, groupsize)
+    sc, ze = scales.reshape(-1, 1), zeros.reshape(-1, 1)
+    q = g.sub(ze - sc * 8).div(sc).round().clamp_(0, 15).to(torch.int32).reshape_as(w)
+    sz = torch.cat([scales.reshape(*scales.shape, 1), zeros.reshape(*zeros.shape, 1)], 2).transpose(0, 1).contiguous()
+    return q, sz
+
+
+def dequantize_int4_groups(q: torch.Tensor, scales_and_zeros: torch.Tensor, groupsize: int = 128) -> torch.Tensor:
+    """group_dequantize_tensor (quantize.py:128-163): (q - 8) * scale + zero, in the dtype of scales_and_zeros."""
+    sc, ze = torch.split(scales_and_zeros.transpose(0, 1), 1, 2)
+    return q.reshape(-1, groupsize).sub(8).mul(sc.reshape(-1, 1)).add(ze.reshape(-1, 1)).reshape_as(q)
+
+
+def quantize_state_int4(cfg: "DualARConfig", state: Dict[str, torch.Tensor], groupsize: int = 128) -> Dict[str, torch.Tensor]:
+    """WeightOnlyInt4QuantHandler.create_quantized_state_dict (quantize.py:310-349) up to -- not including -- the tile
+    shuffle: every nn.Linear weight becomes `<name>.weight_int4` (unshuffled 4-bit values, in_features zero-padded to
+    a multiple of 1024 when groupsize / 128 do not divide it) + `<name>.scales_and_zeros`; embeddings and norms stay."""
+    out = dict(state)
+    for k, v in state.items():
+        if v.dim() == 2 and k.endswith(".weight") and "embeddings" not in k:
+            w = v.to(torch.bfloat16)
+            kin = w.shape[1]
+            if not (kin % groupsize == 0 and kin % 128 == 0):      # _check_linear_int4_k with inner_k_tiles = 8
+                w = F.pad(w, pad=(0, (-kin) % 1024))
+            q, sz = quantize_int4_groups(w, groupsize)
+            del out[k]
+            out[k + "_int4"] = q
+            out[k[: -len("weight")] + "scales_and_zeros"] = sz
+    return out
+
+
 class DualAROracle:
     """Functional restatement of DualARTransformer's generate-time surface (llama.py:660-828).
     A state dict quantised by `quantize_state_int8` runs with WeightOnlyInt8Linear's arithmetic

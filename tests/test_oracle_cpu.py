@@ -149,3 +149,36 @@ def test_int8_weight_only_oracle_vs_reference_golden():
     assert st["exact"] >= 0.9 * st["decisions"]
     _, _, zb = load_dualar_case("tiny")       # quantisation is visible: the traces differ from the bf16 model's
     assert not np.array_equal(z["slow_logits_live"], zb["slow_logits_live"])
+
+
+def test_int4_group_quantiser_restatement_equals_the_reference_functions():
+    """Groundwork for the int4 weight-only format (quantize.py:52-163,300-349; refused by the product path): the
+    restated group quantiser gives, bit for bit, the reference's 4-bit values, packed scales_and_zeros and
+    dequantised weights, including the handler's zero-padding of in_features to a multiple of 1024.  (The CUDA-only
+    tile shuffle `_convert_weight_to_int4pack` and the mm arithmetic cannot be run here and stay unpinned.)"""
+    from oracle.refload import add_reference_to_path
+
+    add_reference_to_path()
+    from tools.llama import quantize as RQ
+
+    torch.manual_seed(3)
+    for shape, gs in (((96, 256), 128), ((64, 1024), 32), ((40, 512), 256)):
+        w = (torch.randn(shape) * 0.05).bfloat16()
+        q, sz = O.quantize_int4_groups(w, gs)
+        rq, rsz = RQ.group_quantize_tensor(w, n_bit=4, groupsize=gs)
+        assert torch.equal(q, rq) and torch.equal(sz, rsz) and sz.shape == (shape[1] // gs, shape[0], 2)
+        assert int(q.min()) >= 0 and int(q.max()) <= 15
+        assert torch.equal(O.dequantize_int4_groups(q, sz.float(), gs), RQ.group_dequantize_tensor(rq, rsz.float(), 4, gs))
+        err = (O.dequantize_int4_groups(q, sz.float(), gs) - w.float()).abs().reshape(-1, gs).amax(1)
+        assert bool((err <= sz[..., 0].float().t().reshape(-1) * 0.51 + 1e-3).all())       # half a step of the group's grid
+    # the handler's padding rule on a whole (tiny) checkpoint: in_features 128 / 256 are not multiples of 1024 -> no
+    # padding needed only when groupsize and 128 divide them
+    cfg = O.DualARConfig()
+    st = O.make_synthetic_state(cfg, seed=1)
+    q4 = O.quantize_state_int4(cfg, st)
+    assert "layers.0.attention.wqkv.weight" not in q4 and q4["layers.0.attention.wqkv.weight_int4"].dtype == torch.int32
+    assert q4["layers.0.attention.wqkv.weight_int4"].shape[1] == cfg.dim            # 128: divisible by 128, no padding
+    assert q4["embeddings.weight"].dtype == torch.bfloat16 and "embeddings.scales_and_zeros" not in q4
+    assert RQ._check_linear_int4_k(cfg.dim, 128, 8) and not RQ._check_linear_int4_k(96, 128, 8)
+    w96 = (torch.randn(16, 96) * 0.05).bfloat16()
+    assert O.quantize_state_int4(cfg, {"x.weight": w96})["x.weight_int4"].shape == (16, 1024)   # padded like the handler
