@@ -41,6 +41,12 @@ def pmc_traffic(batch, frames, int8):
         return None, "profiles/pmc_traffic.json missing"
     if int8 or batch != d.get("batch") or frames != 215:
         return None, "PMC pass was collected for the headline configuration only"
+    from fish_speech_amd.build import decode_sources_sha
+
+    have, want = d.get("decode_sources_sha"), decode_sources_sha()
+    if have != want:   # the kernels changed after the PMC pass: do not quote its figure as this binary's
+        return None, (f"STALE: profiles/pmc_traffic.json ({d['bytes_per_decode_frame']} B per frame) was collected for decode "
+                      f"sources {have}, this tree has {want}; re-run tools/make_profiles.sh <tag> pmc")
     return float(d["bytes_per_decode_frame"]), d.get("source", "")
 
 FRAME_LEN = 2048          # samples per frame (modded_dac.py:833,861)
@@ -220,8 +226,10 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=32, codec_frames=N_FR
     torch.set_num_threads(all_threads)
     return {
         "value": round(10.0 / (t_ar + t_codec), 5), "unit": "audio-sec/s", "cores": max(best, cbest),
+        "cores_dual_ar": best, "cores_codec": cbest,   # each leg runs with the best thread count of its own sweep
         "kind": "port",
-        "sample": f"oracle on torch CPU, batch 1, {best} threads (best of sweep "
+        "sample": f"oracle = the bit-equal CPU port of the reference path (tests/test_oracle_cpu.py; /root/reference itself "
+                  f"is not on this box), torch CPU, batch 1, Dual-AR on {best} threads (best of sweep "
                   f"{ {k: round(v, 2) for k, v in sweep.items()} } s/frame-ish, host has {os.cpu_count()} cpus): "
                   f"prefill {PROMPT_T} tokens {t_prefill:.2f}s + {n_frames} decode "
                   f"frames at context {PROMPT_T}..{PROMPT_T + n_frames} at {per_frame:.3f}s/frame (bf16), extrapolated to "
@@ -428,33 +436,51 @@ def run_config5_staggered(model, codec, cfg, n_req=16, gap_s=0.25):
     utterance streamed on its own chunk schedule, slots refilled as utterances finish.  Reports first-audio latency
     from arrival (p50 / p90 over the requests, queueing for a slot included) and whole-run throughput.  gap_s = 0.25:
     40 audio-seconds demanded per second, about 0.8 of what this loop sustains (at 0.12 s the queue grows without
-    bound and the latency is queueing time: p50 194 ms, p90 399 ms measured).  serve_stream cuts an advance short when
-    a request is about to arrive and a slot is free (admit_early): 81 / 92 -> 55 / 62 ms p50 / p90 at this load together with voicing the newest frame at once."""
+    bound and the latency is queueing time: p50 194 ms, p90 399 ms measured).  Since round 4 the requests are put by a
+    producer thread into a RequestFeed (no knowledge of future arrivals: while a slot is free the live utterances advance
+    `open_slot_step` frames at a time); rounds 2-3 passed a list with known arrival times (55 / 62 ms p50 / p90)."""
     import statistics
+    import threading
 
-    from fish_speech_amd.serving import StreamRequest, serve_stream
+    from fish_speech_amd.serving import RequestFeed, StreamRequest, serve_stream
 
     prompts = make_prompts(cfg, n_req, 7000)
 
     def once():
-        reqs = [StreamRequest(prompt=p, max_new_tokens=N_FRAMES + 1, seed=8000 + i, rid=i, arrival=i * gap_s)
-                for i, p in enumerate(prompts)]
+        # The requests come from a producer THREAD through a RequestFeed, as a server's request threads would put them:
+        # the loop knows nothing about future arrivals (ADVICE r03: the round-3 figure was measured over a request list
+        # with known arrival times, whose `admit_early` cut is clairvoyant).  Latency counts from the put.
+        reqs = [StreamRequest(prompt=p, max_new_tokens=N_FRAMES + 1, seed=8000 + i, rid=i) for i, p in enumerate(prompts)]
+        feed = RequestFeed()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+
+        def producer():
+            for i, r in enumerate(reqs):
+                dt = t0 + i * gap_s - time.perf_counter()
+                if dt > 0:
+                    time.sleep(dt)
+                feed.put(r)
+            feed.close()
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
         first, samples = {}, 0
-        for ev in serve_stream(model=model, codec=codec, requests=reqs, max_batch=BATCH, step_frames=8,
+        for ev in serve_stream(model=model, codec=codec, requests=feed, max_batch=BATCH, step_frames=8,
                                first_chunk_frames=8, chunk_frames=32, chunk_growth=2.0, temperature=0.7, top_p=0.7, top_k=30):
             if ev.kind == "segment":
                 torch.cuda.synchronize()
                 samples += ev.audio.shape[-1]
                 if ev.first_audio_latency is not None:
-                    first[ev.rid] = time.perf_counter() - t0 - ev.rid * gap_s
+                    first[ev.rid] = time.perf_counter() - reqs[ev.rid].arrival_abs
+        th.join()
         return sorted(first.values()), samples, time.perf_counter() - t0
 
     once()
     lat, samples, wall = once()
     return {"workload": f"configs[3]+[4]: {n_req} requests arriving every {int(gap_s * 1e3)} ms, {BATCH} slots, per-utterance "
-                        f"streaming (first chunk 8 frames, then 32, 64, ...) with slot refill (serving.serve_stream)",
+                        f"streaming (first chunk 8 frames, then 32, 64, ...) with slot refill (serving.serve_stream over a "
+                        f"RequestFeed filled by a producer thread: arrivals unknown to the loop)",
             "first_audio_ms_p50": round(statistics.median(lat) * 1e3, 1),
             "first_audio_ms_p90": round(lat[int(0.9 * (len(lat) - 1))] * 1e3, 1),
             "audio_sec_per_s": round(samples / SAMPLE_RATE / wall, 2), "wall_s": round(wall, 3)}

@@ -14,6 +14,18 @@ HEADERS = ["common.h", "dualar_kernels.h", "dac_kernels.h", os.path.join("..", "
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+def decode_sources_sha() -> str:
+    """sha1 over the sources of the Dual-AR decode kernels: what a PMC traffic pass (profiles/pmc_traffic.json) was
+    collected for.  bench.py compares it with the tree it runs from, so a stale figure cannot pass as current."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for name in ("common.h", "dualar_kernels.h", "dualar_kernels.hip", "dualar.hip"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

@@ -67,6 +67,7 @@ struct LinearArgs {
   // nn.Linear bias [N] (only fast_project_in has one, llama.py:666): out = bf16(acc + bias), ONE rounding like torch's
   // addmm; skinny kernel, EPI_STORE only
   const bf16_t* bias;
+  int late_epi;            // A/B measurements only (FMI_GEMV_LATE_EPI): epilogue operands loaded after the last barrier
 };
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s);  // M <= 16
 

@@ -343,14 +343,14 @@ int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf
 //
 // Work-group = WAVES waves, owns TILES 16-row weight tiles over the whole K; wave w owns the k-tile PAIRS
 // [w*P/WAVES, (w+1)*P/WAVES) (P = K/64; the last wave also takes an unpaired last tile).  Per pair a lane issues
-// two 16-byte weight loads per tile (the wave: two contiguous 1 KiB tiles) and the activation fragments:
-//   M <= 8 (PAIRX): ONE all-lanes load of eight full cache lines for the whole pair (see packed_k0), used as the B
-//                   operand of both tiles; tile 0 accumulates in acc0 (valid in columns 0-7), tile 1 in acc1 (valid
-//                   in columns 8-15), acc1 is shifted down 8 columns (DPP row_shl) and added at the end;
-//   M  > 8        : one load per tile (16 rows x 64 B), tile 0 -> acc0, tile 1 -> acc1, added at the end.
-// Both variants multiply the same values in the same order, so a row's result does not depend on the batch it is in.
+// two 16-byte weight loads per tile (the wave: two contiguous 1 KiB tiles) and the activation fragments of the pair with
+// ONE all-lanes load of eight full cache lines per set of 8 rows (see packed_k0), used as the B operand of both tiles:
+// tile 0 accumulates in one accumulator (valid in columns 0-7), tile 1 in a second one (valid in columns 8-15) that is
+// shifted down 8 columns (DPP row_shl) and added at the end.  Rows 8-15 (M > 8, round 4) arrive by a second load and
+// have their own accumulator pair; every row sees the same products in the same order whichever set it arrives in, so a
+// row's result does not depend on the batch it is in.
 // What bounds this kernel is requests in flight per CU, not bytes (tools/gemv_lds_probe.hip): halving the activation
-// requests took w1|w3 21.8 -> 20.6, wqkv 10.4 -> 9.8, wo 7.1 -> 6.5, w2 14.7 -> 13.3 us.
+// requests took w1|w3 21.8 -> 20.6, wqkv 10.4 -> 9.8, wo 7.1 -> 6.5, w2 14.7 -> 13.3 us (round 1).
 // Split-K partials meet in LDS and are summed in wave order (deterministic).
 
 __device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -376,8 +376,18 @@ __device__ inline float dpp_row_shl8(float v) {  // lane n of every 16-lane row 
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x108, 0xf, 0xf, false));
 }
 
+__device__ inline float dpp_row_shr8(float v) {  // lane n of every 16-lane row receives lane n - 8
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x118, 0xf, 0xf, false));
+}
+
+constexpr int SKINNY_XH = 5;   // k-tile pairs of activations a wave can hold (K = 2560 over 8 waves: exactly 5)
+
 // UNR = k-tile pairs in flight per wave; TILES = 16-row weight tiles per work-group (SwiGLU: gate/up tiles
-// alternate, so TILES is even); PAIRX = the M <= 8 activation path.
+// alternate, so TILES is even).
+// XR = activation rows per set of all-lanes loads: 8 (M <= 8: one load of eight full cache lines per pair) or 16
+// (M <= 16, round 4: a second load brings rows 8-15; tile 0 / tile 1 of the pair then accumulate rows 8-15 in a second
+// accumulator pair, columns 0-7 / 8-15 again).  A row's products and their order are the same in both forms and the same
+// whichever of the two loads the row arrives in, so its result does not depend on the batch it is in.
 // Q8: the weights are the int8 tiles of a weight-only-int8 checkpoint (a.wq, launch_pack_weight_int8): one 16-byte
 // load per lane brings both k-tiles of a pair, converted to bf16 in registers (exact: |v| <= 128) right before the
 // same MFMAs -- the products, their order and hence the result bits equal the bf16 kernel on the dequantised
@@ -388,45 +398,108 @@ __device__ inline float dpp_row_shl8(float v) {  // lane n of every 16-lane row 
 // multiplies a 16-row A operand: lanes of rows ROWS..15 re-read row ROWS-1 (same cache lines, no extra request) and
 // their products land in accumulator rows nobody reads.  Rows 0..ROWS-1 see the same products in the same order as
 // in the 16-row layout, so the result bits do not depend on ROWS.
-template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool PAIRX, bool NT = true, bool Q8 = false, int ROWS = 16>
-__global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a) {
+//
+// XH > 0 (round 4, NORM only, K % 64 == 0, at most XH pairs per wave): the wave requests the activation fragments of
+// its WHOLE k-slice first thing (K = 2560: five 16-byte loads per lane and row set) and the RMSNorm statistics come from
+// those registers -- per lane a sequential sum over its chunks, an xor tree over the eight chunk lanes of a row, the
+// waves' partials through LDS summed in wave order (the same tree in every variant, so still batch-invariant).  The
+// round-1..3 prologue read every row twice (a statistics pass over the whole row, then the fragments) with a barrier and
+// a second exposed round trip in between: 40 of the ~160 wave-level loads of a wqkv work-group and ~2 us of every
+// norm-fused launch.  The weight stream runs as a ring of UNR pairs refilled load by load.  Measured in the frame
+// (profiles/r04_gemv_ab.txt): w1|w3 21.1 -> 20.3, wqkv 10.35 -> 9.05, heads 9.0 -> 7.3 us.
+//
+// Epilogue operands that do not depend on the products (residual, int8 row scale, bias) are requested at the top of the
+// kernel: loaded after the last barrier they were one more dependent L2 miss at the tail of every wo / w2 launch.
+template <int WAVES, int EPI, bool NORM, int UNR, int TILES, int XR, bool NT = true, bool Q8 = false, int ROWS = 16, int XH = 0>
+__global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR == 1) ? (XR == 8 ? 6 : 4) : 1) void linear_skinny_kernel(LinearArgs a) {
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
-  static_assert(!Q8 || PAIRX, "the int8 stream is the M <= 8 decode path");
+  static_assert(XR == 8 || XR == 16, "activation row sets of 8");
   static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || (!Q8 && EPI != EPI_SILU)), "row-balanced tiles: bf16, no SwiGLU");
+  static_assert(XH == 0 || NORM, "held activation fragments belong to the norm-fused variants");
+  constexpr int XS = XR / 8;          // all-lanes activation loads per k-tile pair
+  constexpr int XHN = XH > 0 ? XH : 1;
   constexpr int TSTRIDE = ROWS * 4;   // u32x4 per (tile, k-tile): ROWS rows x 4 lane groups
   __shared__ float red[WAVES][TILES][256];
   __shared__ float s_rstd[16];
+  __shared__ float s_part[WAVES][16];
+  __shared__ uint4 s_nw[(XH > 0 ? XH : 0) * WAVES * 8 + 1];   // XH > 0: the norm weight vector (K / 8 chunks of 8)
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: k-slice bounds and their branches go scalar
   const int b = lane & 15, g = lane >> 4;
   const int KT = a.K >> 5, P = KT >> 1;
   const int tile0 = blockIdx.x * TILES;
-  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.wp);
 
   const int pbeg = (int)((int64_t)wave * P / WAVES), pend = (int)((int64_t)(wave + 1) * P / WAVES);
-  const u32x4* wrow[TILES];  // bf16: [KT][64] u32x4 per tile row-block; int8: [P][64] u32x4 (a pair per entry)
-#pragma unroll
-  for (int t = 0; t < TILES; ++t)
-    wrow[t] = Q8 ? reinterpret_cast<const u32x4*>(a.wq) + ((int64_t)(tile0 + t) * P) * 64 + lane
-                 : wp + ((int64_t)(tile0 + t) * KT) * TSTRIDE + (ROWS == 16 ? lane : g * ROWS + min(b, ROWS - 1));
+  // weight addressing: a wave-uniform 64-bit base per (tile, k-tile) + one 32-bit per-lane byte offset (SGPR base +
+  // VGPR offset loads: per-lane 64-bit pointers cost the norm-fused w1|w3 variant its third work-group per CU).
+  // bf16: [tile][KT][TSTRIDE] u32x4; int8: [tile][P][64] u32x4 (a pair per entry)
+  const char* __restrict__ wbase = Q8 ? reinterpret_cast<const char*>(a.wq) : reinterpret_cast<const char*>(a.wp);
+  const uint32_t wlane = (uint32_t)(Q8 || ROWS == 16 ? lane : g * ROWS + min(b, ROWS - 1)) * 16u;
+  auto wptr = [&](int t, int j) -> const u32x4* {   // bf16: k-tile j of tile t; int8: pair j of tile t
+    const int64_t unit = Q8 ? ((int64_t)(tile0 + t) * P + j) * 64 : ((int64_t)(tile0 + t) * KT + j) * TSTRIDE;
+    return reinterpret_cast<const u32x4*>(wbase + unit * 16 + wlane);
+  };
 
-  // the first chunk of weight tiles is issued BEFORE the RMSNorm prologue so that HBM latency overlaps
-  // the row statistics
+  // activation fragment addressing: fetch lane = kt*32 + g'*8 + row -> x[8 s + row][64 p + 32 kt + 8 g' ..] for row
+  // set s; as MFMA B operand that register is column (g'&1)*8 + row, lane group kt*2 + (g'>>1) (see packed_k0)
+  const int f_off = (lane >> 5) * 32 + ((lane >> 3) & 3) * 8;
+  const char* __restrict__ xbase = reinterpret_cast<const char*>(a.x);
+  uint32_t xoff[XS];
+#pragma unroll
+  for (int s = 0; s < XS; ++s) xoff[s] = (uint32_t)(min(s * 8 + (lane & 7), a.M - 1) * a.ldx + f_off) * 2u;
+  auto xptr = [&](int s, int p) -> const uint4* { return reinterpret_cast<const uint4*>(xbase + (int64_t)p * 128 + xoff[s]); };
+  const char* __restrict__ nbase = reinterpret_cast<const char*>(a.norm_w);
+
+  uint4 xh[XS][XHN];   // XH > 0: the wave's activation fragments, raw, then normalised in place
+  if (XH > 0) {
+#pragma unroll
+    for (int u = 0; u < XHN; ++u)
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+        xh[s][u] = *xptr(s, pbeg + u);   // XH > 0: every wave owns exactly XH pairs (launcher)
+  }
+
+  // first weights of the wave: issued BEFORE the RMSNorm prologue so that HBM latency overlaps the row statistics
   u32x4 wa[TILES][UNR][2];
+  auto load_pair = [&](int slot, int p) {
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      if (Q8) {
+        wa[t][slot][0] = wload<NT>(wptr(t, p));
+      } else {
+        wa[t][slot][0] = wload<NT>(wptr(t, 2 * p));
+        wa[t][slot][1] = wload<NT>(wptr(t, 2 * p + 1));
+      }
+    }
+  };
   const int nfull = (pend - pbeg) / UNR;
-  auto load_chunk = [&](int p0) {
+  if (XH > 0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
+      if (u < XHN) load_pair(u, pbeg + u);
+  } else if (nfull > 0) {
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        if (Q8) {
-          wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(p0 + u) * 64);
-        } else {
-          wa[t][u][0] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u)) * TSTRIDE);
-          wa[t][u][1] = wload<NT>(wrow[t] + (int64_t)(2 * (p0 + u) + 1) * TSTRIDE);
-        }
-      }
-  };
+    for (int u = 0; u < UNR; ++u) load_pair(u, pbeg + u);
+  }
+
+  // epilogue operands (see above); a.late_epi (A/B measurements only) loads them where rounds 1-3 did
+  const int e_bb = tid >> 4, e_r = tid & 15;
+  const bool e_on = tid < 256 && e_bb < a.M && e_r < ROWS;
+  constexpr int NRES = EPI == EPI_RESIDUAL ? TILES : 1, NSC = Q8 ? TILES : 1, NBIAS = EPI == EPI_STORE ? TILES : 1;
+  bf16_t e_res[NRES], e_scale[NSC], e_bias[NBIAS];   // (the scale of a bf16-dequantised int8 linear, !Q8, stays a late load)
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    if (t < NRES) e_res[t] = 0;
+    if (t < NSC) e_scale[t] = 0;
+    if (t < NBIAS) e_bias[t] = 0;
+    if (e_on && !a.late_epi) {
+      if (EPI == EPI_RESIDUAL) e_res[t < NRES ? t : 0] = a.res[(int64_t)e_bb * a.ldr + (tile0 + t) * ROWS + e_r];
+      if (Q8 && a.scale) e_scale[t < NSC ? t : 0] = a.scale[(tile0 + t) * 16 + e_r];
+      if (EPI == EPI_STORE && a.bias) e_bias[t < NBIAS ? t : 0] = a.bias[(tile0 + t) * ROWS + e_r];
+    }
+  }
+
   // int8 pair register (tile 0's 8 values | tile 1's 8 values) -> the two bf16 A operands.  One SDWA convert per
   // weight (byte select + sign extension inside v_cvt_f32_i32) and one pack per two: the compiler's own sequence for
   // (float)(int8_t)(w >> 8n) is shift + v_bfe_i32 + convert, 3.5 VALU instructions per weight against 1.5.
@@ -447,101 +520,155 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
 #endif
     }
   };
-  if (nfull > 0) load_chunk(pbeg);
 
-  if (NORM) {
+  float rstd[XS];
+#pragma unroll
+  for (int s = 0; s < XS; ++s) rstd[s] = 0.f;
+  if (NORM && XH > 0) {
+    // the norm weights travel through LDS (one 16-byte load per thread, read back as broadcasts after the statistics
+    // barrier): held in registers next to the fragments they cost the w1|w3 launch its third work-group per CU
+    for (int i = tid; i < (a.K >> 3); i += WAVES * 64) s_nw[i] = reinterpret_cast<const uint4*>(a.norm_w)[i];
+    // sum of squares: lane (chunk c = lane >> 3, row) sequentially over its pairs and elements, then the eight chunk
+    // lanes of the row by an xor tree (c bit 0, 1, 2), then the waves in order
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      float ss = 0.f;
+#pragma unroll
+      for (int u = 0; u < XHN; ++u) {
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&xh[s][u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = bf2f(e[j]);
+          ss = fmaf(f, f, ss);
+        }
+      }
+      ss += __shfl_xor(ss, 8, 64);
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lane < 8) s_part[wave][s * 8 + lane] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tot += s_part[w][s * 8 + (lane & 7)];
+      rstd[s] = rsqrtf(tot / (float)a.K + a.eps);
+#pragma unroll
+      for (int u = 0; u < XHN; ++u) {
+        const bf16x8 nf = norm_frag(xh[s][u], s_nw[(pbeg + u) * 8 + (lane >> 3)], rstd[s]);
+        xh[s][u] = *reinterpret_cast<const uint4*>(&nf);
+      }
+    }
+  } else if (NORM) {
     for (int r = wave; r < a.M; r += WAVES) {
       float v = row_rstd(a.x + (int64_t)r * a.ldx, a.K, a.eps, lane);
       if (lane == 0) s_rstd[r] = v;
     }
     __syncthreads();
-  }
-
-  // activation fragment addressing
-  //   PAIRX: fetch lane = kt*32 + g'*8 + row  -> x[row][64 p + 32 kt + 8 g' ..]; as operand: column (g'&1)*8 + row
-  //   else : operand lane (b, g) of tile t    -> x[b][packed_k0(2p + t, g) ..]
-  const int f_row = PAIRX ? min(lane & 7, a.M - 1) : (b < a.M ? b : 0);
-  const bool bvalid = PAIRX ? true : b < a.M;
-  const int f_off = PAIRX ? (lane >> 5) * 32 + ((lane >> 3) & 3) * 8 : 0;
-  const bf16_t* xrow = a.x + (int64_t)f_row * a.ldx + f_off;
-  const bf16_t* nrow = NORM ? a.norm_w + f_off : nullptr;
-  const float rstd = NORM ? s_rstd[f_row] : 0.f;
-  const int k0_t0 = (g >> 1) * 32 + ((g & 1) << 1) * 8, k0_t1 = k0_t0 + 8;  // packed_k0 inside a pair, tile 0 / 1
-
-  f32x4 acc0[TILES], acc1[TILES];
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) {
-    acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < XS; ++s) rstd[s] = s_rstd[min(s * 8 + (lane & 7), a.M - 1)];
   }
 
-  auto frag = [&](int koff) -> bf16x8 {  // activation (optionally normalised) fragment starting at element koff
-    uint4 xv = bvalid ? *reinterpret_cast<const uint4*>(xrow + koff) : make_uint4(0, 0, 0, 0);
+  f32x4 acc[2 * XS][TILES];   // [2 s + tile-of-pair]: row set s, valid in columns 0-7 (tile 0) / 8-15 (tile 1)
+#pragma unroll
+  for (int i = 0; i < 2 * XS; ++i)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto frag = [&](int s, int p) -> bf16x8 {  // activation (optionally normalised) fragment of k-tile pair p
+    uint4 xv = *xptr(s, p);
     if (NORM) {
-      uint4 nv = *reinterpret_cast<const uint4*>(nrow + koff);
-      return norm_frag(xv, nv, rstd);
+      uint4 nv = *reinterpret_cast<const uint4*>(nbase + (int64_t)p * 128 + (uint32_t)f_off * 2u);
+      return norm_frag(xv, nv, rstd[s]);
     }
     return *reinterpret_cast<bf16x8*>(&xv);
   };
-  auto compute_chunk = [&](int p0) {
-    bf16x8 x0[UNR], x1[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int kb = (p0 + u) * 64;
-      if (PAIRX) {
-        x0[u] = frag(kb);
-        x1[u] = x0[u];
-      } else {
-        x0[u] = frag(kb + k0_t0);
-        x1[u] = frag(kb + k0_t1);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        u32x4 w0 = wa[t][u][0], w1 = wa[t][u][1];
-        if (Q8) unpack_q8(wa[t][u][0], w0, w1);
-        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), x0[u], acc0[t], 0, 0, 0);
-        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), x1[u], acc1[t], 0, 0, 0);
-      }
-  };
-
-  int p = pbeg;
-  for (int c = 0; c < nfull; ++c) {
-    compute_chunk(p);
-    p += UNR;
-    if (c + 1 < nfull) load_chunk(p);
-  }
-  for (; p < pend; ++p) {  // leftover pairs of this wave, one at a time
-    bf16x8 x0, x1;
-    if (PAIRX) {
-      x0 = frag(p * 64);
-      x1 = x0;
-    } else {
-      x0 = frag(p * 64 + k0_t0);
-      x1 = frag(p * 64 + k0_t1);
-    }
+  auto mma_pair = [&](int slot, const bf16x8* xs) {   // one k-tile pair: weights of ring slot `slot`, fragments xs[XS]
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 w0, w1;
-      if (Q8) {
-        const u32x4 q = wload<NT>(wrow[t] + (int64_t)p * 64);
-        unpack_q8(q, w0, w1);
-      } else {
-        w0 = wload<NT>(wrow[t] + (int64_t)(2 * p) * TSTRIDE);
-        w1 = wload<NT>(wrow[t] + (int64_t)(2 * p + 1) * TSTRIDE);
+      u32x4 w0 = wa[t][slot][0], w1 = wa[t][slot][1];
+      if (Q8) unpack_q8(wa[t][slot][0], w0, w1);
+#pragma unroll
+      for (int s = 0; s < XS; ++s) {
+        acc[2 * s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xs[s], acc[2 * s][t], 0, 0, 0);
+        acc[2 * s + 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xs[s], acc[2 * s + 1][t], 0, 0, 0);
       }
-      acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), x0, acc0[t], 0, 0, 0);
-      acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), x1, acc1[t], 0, 0, 0);
+    }
+  };
+
+  if (XH > 0) {
+    // ring of UNR pairs, refilled load by load: a k-tile's register is requested again (for pair u + UNR) right after
+    // the products that consumed it, so the wave never has fewer than (2 TILES UNR - 1) tile loads in flight
+#pragma unroll
+    for (int u = 0; u < XHN; ++u) {
+      const int slot = u % UNR;
+      const bool more = u + UNR < XHN;
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        if (Q8) {
+          u32x4 w0, w1;
+          unpack_q8(wa[t][slot][0], w0, w1);
+          if (more) wa[t][slot][0] = wload<NT>(wptr(t, pbeg + u + UNR));
+#pragma unroll
+          for (int s = 0; s < XS; ++s) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&xh[s][u]);
+            acc[2 * s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xv, acc[2 * s][t], 0, 0, 0);
+            acc[2 * s + 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xv, acc[2 * s + 1][t], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int s = 0; s < XS; ++s)
+              acc[2 * s + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][slot][h]),
+                                                                           *reinterpret_cast<const bf16x8*>(&xh[s][u]), acc[2 * s + h][t], 0, 0, 0);
+            if (more) wa[t][slot][h] = wload<NT>(wptr(t, 2 * (pbeg + u + UNR) + h));
+          }
+        }
+      }
+    }
+  } else {
+    int p = pbeg;
+    for (int c = 0; c < nfull; ++c) {
+      bf16x8 xs[UNR][XS];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int s = 0; s < XS; ++s) xs[u][s] = frag(s, p + u);
+      // every fragment of the chunk is requested before its first product (without this fence the scheduler sinks the
+      // second pair's load below the first pair's products: one more exposed L2 round trip per chunk, wo / w2 +2 us)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) mma_pair(u, xs[u]);
+      p += UNR;
+      if (c + 1 < nfull) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) load_pair(u, p + u);
+      }
+    }
+    for (; p < pend; ++p) {  // leftover pairs of this wave, one at a time
+      bf16x8 xs[XS];
+#pragma unroll
+      for (int s = 0; s < XS; ++s) xs[s] = frag(s, p);
+      load_pair(0, p);
+      mma_pair(0, xs);
     }
   }
-  // fold the two accumulators: PAIRX keeps tile 1's sums in columns 8-15 of the same rows
+  // fold: tile 1's sums sit in columns 8-15 of the same rows; row set 1 (rows 8-15) moves to columns 8-15
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc0[t][j] += PAIRX ? dpp_row_shl8(acc1[t][j]) : acc1[t][j];
-  if (!Q8 && (KT & 1) && wave == WAVES - 1) {  // unpaired last k-tile (plain k order), after the fold: same in both variants
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[0][t][j] + dpp_row_shl8(acc[1][t][j]);
+      if (XS == 2) {
+        const float v1 = acc[2 * (XS - 1)][t][j] + dpp_row_shl8(acc[2 * (XS - 1) + 1][t][j]);
+        const float v1s = dpp_row_shr8(v1);   // every lane executes the DPP move (a disabled source lane reads as invalid)
+        v = (b < 8) ? v : v1s;
+      }
+      acc[0][t][j] = v;
+    }
+  if (!Q8 && (KT & 1) && wave == WAVES - 1) {  // unpaired last k-tile (plain k order), after the fold: same in every variant
     const int kt = KT - 1;
     const int row = b < a.M ? b : 0;
     uint4 xv = *reinterpret_cast<const uint4*>(a.x + (int64_t)row * a.ldx + kt * 32 + g * 8);
@@ -554,86 +681,127 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(LinearArgs a)
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 wv = wload<NT>(wrow[t] + (int64_t)kt * TSTRIDE);
-      acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc0[t], 0, 0, 0);
+      u32x4 wv = wload<NT>(wptr(t, kt));
+      acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[0][t], 0, 0, 0);
     }
   }
 
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc0[t];
+  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[0][t];
   __syncthreads();
 
-  if (tid < 256) {
-    const int bb = tid >> 4, r = tid & 15;  // consecutive threads -> consecutive output columns
-    if (bb < a.M && r < ROWS) {
-      const int ridx = (((r >> 2) * 16) + bb) * 4 + (r & 3);
-      float v[TILES];
+  if (e_on) {
+    const int bb = e_bb, r = e_r;  // consecutive threads -> consecutive output columns
+    const int ridx = (((r >> 2) * 16) + bb) * 4 + (r & 3);
+    float v[TILES];
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) sacc += red[w][t][ridx];
-        if (EPI == EPI_STORE && a.bias) sacc += bf2f(a.bias[(tile0 + t) * ROWS + r]);   // Linear bias: added before the ONE rounding
-        v[t] = rbf(sacc);   // the linear's bf16 output ...
-        if (a.scale) v[t] = rbf(v[t] * bf2f(a.scale[(tile0 + t) * 16 + r]));  // ... times the int8 row scale
+    for (int t = 0; t < TILES; ++t) {
+      bf16_t sc = 0;
+      if (a.late_epi || !Q8) {
+        if (EPI == EPI_RESIDUAL && a.late_epi) e_res[t < NRES ? t : 0] = a.res[(int64_t)bb * a.ldr + (tile0 + t) * ROWS + r];
+        if (a.scale) sc = a.scale[(tile0 + t) * 16 + r];
+        if (EPI == EPI_STORE && a.bias && a.late_epi) e_bias[t < NBIAS ? t : 0] = a.bias[(tile0 + t) * ROWS + r];
+      } else {
+        sc = e_scale[t < NSC ? t : 0];
       }
-      if (EPI == EPI_STORE) {
+      float sacc = 0.f;
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) a.out[(int64_t)bb * a.ldo + (tile0 + t) * ROWS + r] = f2bf(v[t]);
-      } else if (EPI == EPI_RESIDUAL) {
+      for (int w = 0; w < WAVES; ++w) sacc += red[w][t][ridx];
+      if (EPI == EPI_STORE && a.bias) sacc += bf2f(e_bias[t < NBIAS ? t : 0]);   // Linear bias: added before the ONE rounding
+      v[t] = rbf(sacc);   // the linear's bf16 output ...
+      if (a.scale) v[t] = rbf(v[t] * bf2f(sc));  // ... times the int8 row scale
+    }
+    if (EPI == EPI_STORE) {
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-          const int n = (tile0 + t) * ROWS + r;
-          a.out[(int64_t)bb * a.ldo + n] = f2bf(bf2f(a.res[(int64_t)bb * a.ldr + n]) + v[t]);
-        }
-      } else {  // SwiGLU: even tiles = gate rows, odd tiles = up rows (llama.py:987)
+      for (int t = 0; t < TILES; ++t) a.out[(int64_t)bb * a.ldo + (tile0 + t) * ROWS + r] = f2bf(v[t]);
+    } else if (EPI == EPI_RESIDUAL) {
 #pragma unroll
-        for (int t = 0; t < TILES; t += 2) {
-          const int n = ((tile0 + t) >> 1) * 16 + r;
-          float gate = rbf(silu_f(v[t]));
-          float up = v[t + 1 < TILES ? t + 1 : t];
-          a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
-        }
+      for (int t = 0; t < TILES; ++t)
+        a.out[(int64_t)bb * a.ldo + (tile0 + t) * ROWS + r] = f2bf(bf2f(e_res[t < NRES ? t : 0]) + v[t]);
+    } else {  // SwiGLU: even tiles = gate rows, odd tiles = up rows (llama.py:987)
+#pragma unroll
+      for (int t = 0; t < TILES; t += 2) {
+        const int n = ((tile0 + t) >> 1) * 16 + r;
+        float gate = rbf(silu_f(v[t]));
+        float up = v[t + 1 < TILES ? t + 1 : t];
+        a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
       }
     }
   }
 }
 
+// FMI_GEMV_NOHOLD=1: the norm-fused variants keep the round-3 prologue (statistics pass, then fragments); A/B runs
+static bool skinny_hold_enabled() {
+  static const bool off = []() { const char* e = getenv("FMI_GEMV_NOHOLD"); return e && atoi(e) != 0; }();
+  return !off;
+}
+static bool skinny_late_epi() {   // FMI_GEMV_LATE_EPI=1: residual / scale / bias loaded in the epilogue as in rounds 1-3
+  static const bool on = []() { const char* e = getenv("FMI_GEMV_LATE_EPI"); return e && atoi(e) != 0; }();
+  return on;
+}
+static bool skinny_can_hold(const LinearArgs& a, int waves) {
+  return a.norm_w != nullptr && (a.K % 64) == 0 && a.K / 64 == SKINNY_XH * waves && skinny_hold_enabled();
+}
+
 template <int WAVES, int UNR, int TILES>
-static int launch_skinny_t(const LinearArgs& a, hipStream_t s) {
+static int launch_skinny_t(const LinearArgs& a0, hipStream_t s) {
+  LinearArgs a = a0;
+  a.late_epi = skinny_late_epi() ? 1 : 0;
   const bool norm = a.norm_w != nullptr;
-  const bool pairx = a.M <= 8;
+  const bool wide = a.M > 8;
+  const bool hold = skinny_can_hold(a, WAVES);
   dim3 grid(a.N / (16 * TILES)), block(WAVES * 64);
-#define FMI_LAUNCH(EPI_, NORM_)                                                                                     \
-  do {                                                                                                              \
-    if (pairx) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, false>), grid, block, 0, s, a);   \
+#define FMI_LAUNCH_X(EPI_, NORM_, XH_)                                                                                       \
+  do {                                                                                                                      \
+    if (wide) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 16, true, false, 16, XH_>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 8, true, false, 16, XH_>), grid, block, 0, s, a);       \
   } while (0)
-#define FMI_LAUNCH_Q8(EPI_, NORM_) \
-  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true, true, true>), grid, block, 0, s, a)
-  if (a.wq && pairx && (a.K % 64) == 0) {   // weight-only int8 checkpoint: stream the int8 tiles
-    if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH_Q8(EPI_STORE, true); else FMI_LAUNCH_Q8(EPI_STORE, false); }
-    else if (a.epi == EPI_RESIDUAL) { if (norm) FMI_LAUNCH_Q8(EPI_RESIDUAL, true); else FMI_LAUNCH_Q8(EPI_RESIDUAL, false); }
-    else if constexpr (TILES % 2 == 0) { if (norm) FMI_LAUNCH_Q8(EPI_SILU, true); else FMI_LAUNCH_Q8(EPI_SILU, false); }
-  } else if (a.epi == EPI_STORE) { if (norm) FMI_LAUNCH(EPI_STORE, true); else FMI_LAUNCH(EPI_STORE, false); }
-  else if (a.epi == EPI_RESIDUAL) { if (norm) FMI_LAUNCH(EPI_RESIDUAL, true); else FMI_LAUNCH(EPI_RESIDUAL, false); }
-  else if constexpr (TILES % 2 == 0) { if (norm) FMI_LAUNCH(EPI_SILU, true); else FMI_LAUNCH(EPI_SILU, false); }
+#define FMI_LAUNCH(EPI_)                                          \
+  do {                                                            \
+    if (!norm) FMI_LAUNCH_X(EPI_, false, 0);                      \
+    else if (hold) FMI_LAUNCH_X(EPI_, true, SKINNY_XH);           \
+    else FMI_LAUNCH_X(EPI_, true, 0);                             \
+  } while (0)
+#define FMI_LAUNCH_Q8(EPI_)                                                                                                  \
+  do {                                                                                                                      \
+    if (!norm) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, false, UNR, TILES, 8, true, true, 16, 0>), grid, block, 0, s, a); \
+    else if (hold) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, true, UNR, TILES, 8, true, true, 16, SKINNY_XH>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, true, UNR, TILES, 8, true, true, 16, 0>), grid, block, 0, s, a); \
+  } while (0)
+  if (a.wq && !wide && (a.K % 64) == 0) {   // weight-only int8 checkpoint: stream the int8 tiles
+    if (a.epi == EPI_STORE) FMI_LAUNCH_Q8(EPI_STORE);
+    else if (a.epi == EPI_RESIDUAL) FMI_LAUNCH_Q8(EPI_RESIDUAL);
+    else if constexpr (TILES % 2 == 0) FMI_LAUNCH_Q8(EPI_SILU);
+  } else if (a.epi == EPI_STORE) FMI_LAUNCH(EPI_STORE);
+  else if (a.epi == EPI_RESIDUAL) FMI_LAUNCH(EPI_RESIDUAL);
+  else if constexpr (TILES % 2 == 0) FMI_LAUNCH(EPI_SILU);
 #undef FMI_LAUNCH
+#undef FMI_LAUNCH_X
 #undef FMI_LAUNCH_Q8
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
 
-// Row-balanced variants (M <= 8, bf16): the instantiations that exist, i.e. the S2-Pro decode shapes whose 16-row
+// Row-balanced variants (bf16): the instantiations that exist, i.e. the S2-Pro decode shapes whose 16-row
 // tilings leave CUs idle -- wo / w2 (N = 2560: 10 rows x 256 work-groups) and wqkv (N = 6144: 2 x 12 rows x 256).
 // Measured on MI355X (tools/gemv_rows_bench.hip, profiles/r03_gemv_rows_bench.txt), bit-identical outputs:
 // wo 6.5-6.6 -> 6.3 us, w2 12.4-14.7 -> 12.2, wqkv 10.3-10.5 -> 10.05; decode frame 4.73 -> 4.60 ms.
+// Round 4: batches of 9-16 rows stream the same copies (XR = 16).
 template <int WAVES, int UNR, int TILES, int ROWS, int EPI_, bool NORM_>
 static int launch_skinny_rows(const LinearArgs& a, const RowPlan& p, hipStream_t s) {
   LinearArgs b = a;
   b.wp = a.wr;
-  hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, true, true, false, ROWS>), dim3(p.wgs),
-                     dim3(WAVES * 64), 0, s, b);
+  b.late_epi = skinny_late_epi() ? 1 : 0;
+  constexpr int XH_ = NORM_ ? SKINNY_XH : 0;
+  const bool hold = NORM_ && skinny_can_hold(a, WAVES);
+  const dim3 grid(p.wgs), block(WAVES * 64);
+  if (a.M > 8) {
+    if (hold) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 16, true, false, ROWS, XH_>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 16, true, false, ROWS, 0>), grid, block, 0, s, b);
+  } else {
+    if (hold) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 8, true, false, ROWS, XH_>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 8, true, false, ROWS, 0>), grid, block, 0, s, b);
+  }
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -661,7 +829,7 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_skinny: SwiGLU needs N %% 32");
   const int KT = a.K / 32;
   const int ntile = a.N / 16;
-  if (a.wr && a.M <= 8 && !a.wq && !a.scale && skinny_rows_supported(a.N, a.K, a.epi, a.norm_w != nullptr)) {
+  if (a.wr && !a.wq && !a.scale && !a.bias && skinny_rows_supported(a.N, a.K, a.epi, a.norm_w != nullptr)) {
     const RowPlan p = skinny_row_plan(a.N, a.K, a.epi);
     if (a.epi == EPI_RESIDUAL) return launch_skinny_rows<8, 2, 1, 10, EPI_RESIDUAL, false>(a, p, s);
     return launch_skinny_rows<8, 1, 2, 12, EPI_STORE, true>(a, p, s);
@@ -692,6 +860,7 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   }
   return launch_skinny_t<8, 2, 1>(a, s);  // wo, w2, LM head
 }
+
 
 // =====================================================================================
 // tiled linear (any M; prefill): 128x128 block, 4 waves (2x2), each 64x64 = 4x4 MFMA tiles.

@@ -230,8 +230,10 @@ class MiDualAR:
         self._seed_counter = itertools.count()
         # One generation call at a time per model: slots, workspaces and graphs of a handle are shared state (the
         # reference serialises LLM work through its single-worker queue, inference.py:748-799).  Entry points that
-        # own a whole request (engine.StreamingTTSEngine.inference) hold this lock for its duration.
-        self.lock = threading.RLock()
+        # own a whole request (engine.StreamingTTSEngine.inference) hold this lock for its duration.  NOT re-entrant and not
+        # owned by a thread: a generator that holds it across yields may be advanced, closed or finalised from another
+        # thread, and two requests interleaved on ONE thread must exclude each other too.
+        self.lock = threading.Lock()
         self._dtype_probe = torch.empty(0, dtype=torch.bfloat16, device=self.device)
         self.fixed_temperature = torch.tensor(0.7, device=self.device)
         self.fixed_top_p = torch.tensor(0.7, device=self.device)
@@ -381,6 +383,8 @@ class MiDualAR:
         which is what survives the reference's semantic_logit_bias anyway -- and hidden_states (1, 1, fast_dim):
         what the fast transformer is handed, i.e. after `fast_project_in` when fast_dim != dim (llama.py:827)."""
         cfg = self.config
+        if audio_parts is not None:   # llama.py:423-433: no audio_projector exists upstream either; it warns and goes on
+            _warn_audio_parts()
         if not self._cache_setup_done:
             self.setup_caches(1, cfg.max_seq_len)
         ncb1 = cfg.num_codebooks + 1
@@ -626,6 +630,13 @@ def _require_default_bias(model: MiDualAR, bias: torch.Tensor):
     model._bias_ok = key
 
 
+def _warn_audio_parts() -> None:
+    """The reference's own words (llama.py:433): S2 has no audio_projector, the argument is dead upstream too."""
+    import logging
+
+    logging.getLogger("fish_speech_amd").warning("audio_parts provided but model has no audio_projector")
+
+
 def decode_one_token(model: MiDualAR, x: torch.Tensor, input_pos: torch.Tensor, temperature, top_p, top_k: int,
                      semantic_logit_bias=None, audio_masks=None, audio_parts=None,
                      previous_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -634,6 +645,8 @@ def decode_one_token(model: MiDualAR, x: torch.Tensor, input_pos: torch.Tensor, 
     scored: the algorithmic minimum of the reference's -inf bias); passing that very mask is accepted, any other
     bias raises NotImplementedError instead of being ignored; audio_* are dead for S2."""
     ncb1 = model.config.num_codebooks + 1
+    if audio_parts is not None:
+        _warn_audio_parts()
     if semantic_logit_bias is not None:
         _require_default_bias(model, semantic_logit_bias)
     xs = x.reshape(ncb1, -1).t().to(device=model.device, dtype=torch.int32).contiguous()
@@ -658,6 +671,8 @@ def generate(*, model: MiDualAR, prompt: torch.Tensor, max_new_tokens: int, audi
     frames advance by hipGraph replay and <|im_end|> is polled every ``poll_every`` frames.  ``reuse_prefix``: keep
     the slot's K/V afterwards and, next time, run only the prompt columns beyond the longest prefix it shares with
     this prompt (generate_long's chunks repeat the whole conversation so far) -- results are bit-identical."""
+    if audio_parts is not None:
+        _warn_audio_parts()
     return generate_batch(model=model, prompts=[prompt], max_new_tokens=max_new_tokens, poll_every=poll_every,
                           seeds=None if seed is None else [seed], stop_on_im_end=stop_on_im_end,
                           reuse_prefix=reuse_prefix, **sampling_kwargs)[0]

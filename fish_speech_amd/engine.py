@@ -72,6 +72,7 @@ class StreamingTTSEngine(ReferenceLoader, VQManager):
     def __init__(self, model, codec, precision=torch.bfloat16):
         super().__init__()
         self.model, self.decoder_model, self.precision = model, codec, precision
+        self.lock_timeout = 600.0     # seconds a request waits for the model before it reports an error
 
     @torch.no_grad()
     def inference(self, req: TTSRequest) -> Iterator[InferenceResult]:
@@ -80,8 +81,20 @@ class StreamingTTSEngine(ReferenceLoader, VQManager):
         one after the other -- the reference serialises them through its single-worker llama queue.  A consumer that
         abandons the generator must `close()` it (a `for` loop that breaks does)."""
         model, codec = self.model, self.decoder_model
-        with getattr(model, "lock", None) or contextlib.nullcontext():
+        lock = getattr(model, "lock", None)
+        # explicit acquire / release (not `with`): the lock is a plain threading.Lock, so whichever thread runs the
+        # generator's last step (next(), close() or finalisation) may release it, and a second request started on the
+        # SAME thread while this one is suspended waits (and reports a timeout) instead of sharing slot 0
+        if lock is not None and not lock.acquire(timeout=self.lock_timeout):
+            yield InferenceResult("error", None, TimeoutError(
+                f"the model stayed busy for {self.lock_timeout:.0f} s (another request holds it; a suspended generator on "
+                "this very thread would never release it)"))
+            return
+        try:
             yield from self._inference_locked(req, model, codec)
+        finally:
+            if lock is not None:
+                lock.release()
 
     def _inference_locked(self, req: TTSRequest, model, codec) -> Iterator[InferenceResult]:
         sample_rate = codec.sample_rate
@@ -188,6 +201,7 @@ class BatchingTTSEngine(StreamingTTSEngine):
             try:
                 with getattr(model, "lock", None) or contextlib.nullcontext(), torch.no_grad(), \
                         torch.autocast("cuda", dtype=self.precision, enabled=self.precision is not None):
+                    # (the serving thread acquires and releases on itself: `with` is fine here)
                     for ev in serve_stream(model=model, codec=codec, requests=self._feed, max_batch=self.max_batch,
                                            step_frames=self.step_frames, return_when_idle=True):
                         q = self._queues.get(ev.rid)

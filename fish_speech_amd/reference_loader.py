@@ -5,12 +5,12 @@
 Same method names, arguments, cache keys, validation and error types as upstream; what differs is audio I/O:
 torchaudio is not in this image, so `load_audio` reads wav bytes / files with scipy and resamples with a polyphase
 filter (host plumbing outside the hot path; mp3 / flac / ... references raise a clear error instead of being
-mis-decoded).  `engine.StreamingTTSEngine` inherits both, like `TTSInferenceEngine` does."""
+mis-decoded).  `engine.StreamingTTSEngine` inherits both, like `TTSInferenceEngine` does.  The reference-management
+routes of the HTTP server (`add_reference` / `delete_reference` / `list_reference_ids`) are control plane and are not mirrored."""
 from __future__ import annotations
 
 import io
 import re
-import shutil
 from hashlib import sha256
 from pathlib import Path
 from typing import Callable, List, Literal, Tuple
@@ -126,55 +126,13 @@ class ReferenceLoader:
             raise ValueError("only RIFF/WAVE reference audio can be decoded without torchaudio "
                              f"(scipy.io.wavfile: {e})") from e
         x = data.astype(np.float32)
-        if np.issubdtype(data.dtype, np.integer):
-            x /= float(np.iinfo(data.dtype).max)
+        if data.dtype == np.uint8:           # 8-bit PCM is unsigned: (x - 128) / 128, as torchaudio / soundfile decode it
+            x = (x - 128.0) / 128.0
+        elif np.issubdtype(data.dtype, np.integer):
+            x /= float(2 ** (8 * data.dtype.itemsize - 1))   # 1 / 32768 for int16, not 1 / iinfo.max
         if x.ndim == 2:
             x = x.mean(axis=1)
         if original_sr != sr:
             g = int(np.gcd(int(original_sr), int(sr)))
             x = resample_poly(x, sr // g, original_sr // g).astype(np.float32)
         return np.ascontiguousarray(x.squeeze(), dtype=np.float32)
-
-    def list_reference_ids(self) -> List[str]:
-        base = Path(self.references_root)
-        if not base.exists():
-            return []
-        out = []
-        for d in base.iterdir():
-            if not d.is_dir():
-                continue
-            audio = list_files(d, AUDIO_EXTENSIONS, recursive=False, sort=False)
-            if any(a.with_suffix(".lab").exists() for a in audio):
-                out.append(d.name)
-        return sorted(out)
-
-    def add_reference(self, id: str, wav_file_path: str, reference_text: str) -> None:
-        self._validate_id(id)
-        ref_dir = Path(self.references_root) / id
-        if ref_dir.exists():
-            raise FileExistsError(f"Reference ID '{id}' already exists")
-        audio_path = Path(wav_file_path)
-        if not audio_path.exists():
-            raise FileNotFoundError(f"Audio file not found: {wav_file_path}")
-        if audio_path.suffix.lower() not in AUDIO_EXTENSIONS:
-            raise ValueError(f"Unsupported audio format: {audio_path.suffix}. Supported formats: {', '.join(AUDIO_EXTENSIONS)}")
-        try:
-            ref_dir.mkdir(parents=True, exist_ok=False)
-            shutil.copy2(audio_path, ref_dir / f"sample{audio_path.suffix}")
-            (ref_dir / "sample.lab").write_text(reference_text, encoding="utf-8")
-            self.ref_by_id.pop(id, None)
-        except Exception:
-            if ref_dir.exists():
-                shutil.rmtree(ref_dir)
-            raise
-
-    def delete_reference(self, id: str) -> None:
-        self._validate_id(id)
-        ref_dir = Path(self.references_root) / id
-        if not ref_dir.exists():
-            raise FileNotFoundError(f"Reference ID '{id}' does not exist")
-        try:
-            shutil.rmtree(ref_dir)
-            self.ref_by_id.pop(id, None)
-        except Exception as e:
-            raise OSError(f"Failed to delete reference '{id}': {e}")

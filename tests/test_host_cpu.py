@@ -255,7 +255,7 @@ def test_serve_stream_refills_slots_and_every_utterance_equals_its_offline_resul
 
 def test_reference_loader_and_vq_manager_mirror_the_reference_semantics(tmp_path):
     """inference_engine/reference_loader.py:23-260 + vq_manager.py:16-53 over a codec object: references by id (a
-    folder of wav + .lab pairs) and by content hash, both caches, id validation, add / list / delete, and the engine
+    folder of wav + .lab pairs) and by content hash, both caches, id validation, PCM scaling, and the engine
     resolving `reference_id` / `references` the way TTSInferenceEngine.inference does."""
     import io
     from types import SimpleNamespace
@@ -280,12 +280,11 @@ def test_reference_loader_and_vq_manager_mirror_the_reference_semantics(tmp_path
     wavfile.write(str(src), sr // 2, a[::2].copy())                    # half the rate: load_audio resamples
     with pytest.raises(ValueError):
         eng.load_by_id("../etc", "off")
-    with pytest.raises(FileNotFoundError):
-        eng.add_reference("alice", str(tmp_path / "nope.wav"), "x")
-    eng.add_reference("alice", str(src), "hello from alice")
-    with pytest.raises(FileExistsError):
-        eng.add_reference("alice", str(src), "again")
-    assert eng.list_reference_ids() == ["alice"]
+    # (the HTTP server's add / delete / list routes are control plane and not mirrored: the folder is laid out by hand)
+    (eng.references_root / "alice").mkdir(parents=True)
+    (eng.references_root / "alice" / "sample.wav").write_bytes(src.read_bytes())
+    (eng.references_root / "alice" / "sample.lab").write_text("hello from alice", encoding="utf-8")
+    assert not hasattr(eng, "add_reference") and not hasattr(eng, "delete_reference")
     toks, texts = eng.load_by_id("alice", "on")
     assert texts == ["hello from alice"] and len(toks) == 1 and toks[0].shape[0] == NCB
     n_frames = -(-(len(a[::2]) * 2) // codec.frame_length)
@@ -309,11 +308,15 @@ def test_reference_loader_and_vq_manager_mirror_the_reference_semantics(tmp_path
     assert res[-1].code == "final"
     res = list(eng.inference(TTSRequest(text="hi", references=[ref], max_new_tokens=8, seed=3)))
     assert res[-1].code == "final"
-    eng.delete_reference("alice")
-    assert eng.list_reference_ids() == [] and "alice" not in eng.ref_by_id
-    with pytest.raises(FileNotFoundError):
-        eng.delete_reference("alice")
     assert isinstance(eng, ReferenceLoader)
+    # integer PCM is scaled by 2^(bits-1) like torchaudio / soundfile (32768 for int16, not 32767); 8-bit PCM is
+    # unsigned and re-centred: (x - 128) / 128
+    b16 = io.BytesIO()
+    wavfile.write(b16, sr, np.array([-32768, -16384, 0, 16384, 32767], dtype=np.int16))
+    assert np.array_equal(eng.load_audio(b16.getvalue(), sr), np.array([-1.0, -0.5, 0.0, 0.5, 32767 / 32768], dtype=np.float32))
+    b8 = io.BytesIO()
+    wavfile.write(b8, sr, np.array([0, 64, 128, 192, 255], dtype=np.uint8))
+    assert np.array_equal(eng.load_audio(b8.getvalue(), sr), np.array([-1.0, -0.5, 0.0, 0.5, 127 / 128], dtype=np.float32))
 
 
 def test_generate_stream_argument_errors():
@@ -404,6 +407,50 @@ def test_serve_stream_over_a_request_feed_per_request_parameters_and_cancellatio
 
 
 @pytest.mark.timeout(60)
+def test_engine_lock_excludes_interleaved_generators_and_may_be_released_by_another_thread():
+    """`inference()` holds the model's lock across yields.  (a) Two requests interleaved on ONE thread must
+    not both drive slot 0: the second reports an error result (after `lock_timeout`) instead of passing a re-entrant
+    lock and corrupting the first one's audio, and the first still yields exactly its own result.  (b) A generator that
+    was advanced on one thread may be closed from another (thread-pool iteration of a streaming response): the lock
+    is released there and the next request runs."""
+    import threading
+
+    model, codec = StubDualAR(max_batch=1), StubCodec()
+    model.lock = threading.Lock()
+    eng = StreamingTTSEngine(model, codec, precision=None)
+    eng.lock_timeout = 0.2
+    mk = lambda seed: TTSRequest(text="hello there", streaming=True, max_new_tokens=64, seed=seed, first_chunk_frames=2, chunk_frames=3)  # noqa: E731
+    want = list(eng.inference(mk(3)))
+    g1 = eng.inference(mk(3))
+    first = [next(g1), next(g1)]                       # header + first segment: the lock is held now
+    g2 = eng.inference(mk(4))
+    res2 = list(g2)                                     # same thread, first request suspended
+    assert [r.code for r in res2] == ["error"] and isinstance(res2[0].error, TimeoutError)
+    rest = list(g1)
+    got = first + rest
+    assert [r.code for r in got] == [r.code for r in want]
+    assert np.array_equal(got[-1].audio[1], want[-1].audio[1])
+    assert model.lock.acquire(blocking=False)
+    model.lock.release()
+    # (b) advanced here, closed on another thread
+    g3 = eng.inference(mk(5))
+    assert next(g3).code == "header" and next(g3).code == "segment" and model.lock.locked()
+    err = []
+
+    def closer():
+        try:
+            g3.close()
+        except Exception as e:   # noqa: BLE001
+            err.append(e)
+
+    t = threading.Thread(target=closer)
+    t.start()
+    t.join(10)
+    assert not err and not model.lock.locked() and not model.slots
+    assert list(eng.inference(mk(3)))[-1].code == "final"
+
+
+@pytest.mark.timeout(60)
 def test_batching_engine_serves_concurrent_requests_through_one_loop():
     """BatchingTTSEngine: request threads share one serve_stream loop (continuous batching) instead of taking turns;
     every request's result equals the serial engine's, the protocol is unchanged, several utterances were in flight
@@ -416,7 +463,7 @@ def test_batching_engine_serves_concurrent_requests_through_one_loop():
     codec = StubCodec()
     serial = StreamingTTSEngine(StubDualAR(max_batch=1), codec, precision=None)
     model = StubDualAR(max_batch=4)
-    model.lock = threading.RLock()
+    model.lock = threading.Lock()
     peak = [0]
     orig_decode = model.decode
 

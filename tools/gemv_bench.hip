@@ -1,10 +1,15 @@
-// gemv_bench.hip -- micro-benchmark of the skinny (decode) linear kernel variants on MI355X.
+// gemv_bench.hip -- micro-benchmark of the skinny (decode) linear on MI355X: the SHIPPED launcher per S2-Pro shape
+// (row-balanced copies included, as the frame runs them) at M = 1 / 8 / 12 / 16, next to a bare streaming read of the
+// same bytes.  Kernel variants are selected by the launcher's environment switches, so A/B = two runs:
+//   FMI_GEMV_NOHOLD=1    norm-fused variants with the round-3 prologue (statistics pass + fragments)
+//   FMI_GEMV_LATE_EPI=1  residual / scale / bias loaded after the last barrier (rounds 1-3)
 // Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemv_bench.hip \
-//                               fish_speech_amd/csrc/common.cpp -o /tmp/gemv_bench && /tmp/gemv_bench
-// Each variant streams NBUF distinct weight copies round-robin (no cache reuse) and is timed with HIP
-// events over many launches; a pure streaming-read kernel gives the achievable-HBM ceiling of the box.
+//                               fish_speech_amd/csrc/common.cpp -o tools/bin/gemv_bench && tools/bin/gemv_bench
+// Every launch streams a different weight copy (round-robin over ~2 GB: no cache reuse).  GEMV_CHECK=1 also compares
+// every row of the M = 8 / 16 results with the M = 1 result of that row (batch invariance, bit for bit).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "../fish_speech_amd/csrc/dualar_kernels.hip"
 
@@ -22,101 +27,105 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restric
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345) sink[0] = 1;
 }
 
+__global__ void fill_kernel(bf16_t* p, size_t n, uint32_t seed, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = (uint32_t)i * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  p[i] = f2bf(((float)(x & 0xffff) / 32768.f - 1.f) * scale);
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 struct Shape { const char* name; int N, K, epi; bool norm; };
 
-template <int WAVES, int EPI, bool NORM, int UNR, int TILES, bool NT, bool PX = true>
-float run_variant(const Shape& sh, std::vector<bf16_t*>& wbufs, bf16_t* x, bf16_t* nw, bf16_t* res, bf16_t* out, int M, int iters) {
-  LinearArgs a{};
-  a.x = x; a.ldx = sh.K; a.norm_w = NORM ? nw : nullptr; a.eps = 1e-6f; a.res = res; a.M = M; a.N = sh.N; a.K = sh.K; a.epi = EPI;
-  const int n_out = EPI == EPI_SILU ? sh.N / 2 : sh.N;
-  a.ldr = n_out; a.out = out; a.ldo = n_out;
-  if ((sh.N / 16) % TILES) return -1.f;
-  dim3 grid(sh.N / (16 * TILES)), block(WAVES * 64);
+static float time_launches(LinearArgs a, const std::vector<bf16_t*>& w16, const std::vector<bf16_t*>& wr, int iters) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) { a.wp = wbufs[w % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, PX, NT>), grid, block, 0, 0, a); }
+  for (int w = 0; w < 3; ++w) { a.wp = w16[w % w16.size()]; a.wr = wr.empty() ? nullptr : wr[w % wr.size()]; launch_linear_skinny(a, 0); }
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) { a.wp = wbufs[i % wbufs.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, PX, NT>), grid, block, 0, 0, a); }
+  for (int i = 0; i < iters; ++i) { a.wp = w16[i % w16.size()]; a.wr = wr.empty() ? nullptr : wr[i % wr.size()]; launch_linear_skinny(a, 0); }
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   return ms * 1e3f / iters;
 }
-
-#define V(W, U, T, NTF) do { float us = (sh.epi == EPI_SILU) ? run_variant<W, EPI_SILU, true, U, (T < 2 ? 2 : T), NTF>(sh, wbufs, x, nw, res, out, M, iters) \
-    : (sh.epi == EPI_RESIDUAL ? run_variant<W, EPI_RESIDUAL, false, U, T, NTF>(sh, wbufs, x, nw, res, out, M, iters) \
-    : run_variant<W, EPI_STORE, true, U, T, NTF>(sh, wbufs, x, nw, res, out, M, iters)); \
-    if (us > 0) { printf("  W=%2d PAIRS=%d TILES=%d nt=%d : %7.2f us  %6.0f GB/s\n", W, U, (sh.epi == EPI_SILU && T < 2) ? 2 : T, (int)NTF, us, bytes / us * 1e-3); fflush(stdout); } } while (0)
-
-static float run_shipped(const Shape& sh, std::vector<bf16_t*>& wbufs, bf16_t* x, bf16_t* nw, bf16_t* res, bf16_t* out, int M, int iters) {
-  LinearArgs a{};
-  a.x = x; a.ldx = sh.K; a.norm_w = sh.norm ? nw : nullptr; a.eps = 1e-6f; a.res = res; a.M = M; a.N = sh.N; a.K = sh.K; a.epi = sh.epi;
-  const int n_out = sh.epi == EPI_SILU ? sh.N / 2 : sh.N;
-  a.ldr = n_out; a.out = out; a.ldo = n_out;
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) { a.wp = wbufs[w % wbufs.size()]; launch_linear_skinny(a, 0); }
-  CK(hipDeviceSynchronize());
-  CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) { a.wp = wbufs[i % wbufs.size()]; launch_linear_skinny(a, 0); }
-  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  return ms * 1e3f / iters;
-}
-
-#define VX(W, U, T) do { float a_ = (sh.epi == EPI_SILU) ? run_variant<W, EPI_SILU, true, U, (T < 2 ? 2 : T), true, false>(sh, wbufs, x, nw, res, out, M, iters) \
-    : (sh.epi == EPI_RESIDUAL ? run_variant<W, EPI_RESIDUAL, false, U, T, true, false>(sh, wbufs, x, nw, res, out, M, iters) \
-    : run_variant<W, EPI_STORE, true, U, T, true, false>(sh, wbufs, x, nw, res, out, M, iters)); \
-    if (a_ > 0) { printf("  W=%2d PAIRS=%d TILES=%d per-tile activation loads : %7.2f us\n", W, U, T, a_); fflush(stdout); } } while (0)
 
 int main() {
-  const int M = 8, iters = 200;
+  const int iters = 200;
+  const bool check = getenv("GEMV_CHECK") != nullptr;
   const size_t stream_bytes = (size_t)1 << 30;
   void* big; CK(hipMalloc(&big, stream_bytes)); CK(hipMemset(big, 1, stream_bytes));
   uint32_t* sink; CK(hipMalloc((void**)&sink, 4));
-  const bool quick = getenv("GEMV_QUICK") != nullptr;   // only the GEMV variants of w13 / wo
-  for (int blocks : {1024, 2048, 4096, 8192}) {
-    if (quick) break;
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(256), 0, 0, (const u32x4*)big, stream_bytes / 16, sink);
-    CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(256), 0, 0, (const u32x4*)big, stream_bytes / 16, sink);
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("stream read 1 GiB, %d blocks: %.0f GB/s\n", blocks, stream_bytes * 10 / (ms * 1e-3) * 1e-9);
-  }
-  // small streaming reads (the size of one GEMV) to see the fixed per-kernel cost
   for (size_t mb : {21, 32, 50, 100}) {
-    if (quick) break;
     size_t bytes = mb << 20; hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
     for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, 0, (const u32x4*)((char*)big + (size_t)(i % 8) * (128 << 20)), bytes / 16, sink);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("stream read %zu MiB per launch: %.2f us/launch, %.0f GB/s\n", mb, ms * 10, bytes * 100 / (ms * 1e-3) * 1e-9);
   }
+  hipFree(big);
   Shape shapes[] = {{"w13  N=19456 K=2560 swiglu+norm", 19456, 2560, EPI_SILU, true}, {"wqkv N=6144 K=2560 store+norm", 6144, 2560, EPI_STORE, true},
                     {"wo   N=2560 K=4096 residual", 2560, 4096, EPI_RESIDUAL, false}, {"w2   N=2560 K=9728 residual", 2560, 9728, EPI_RESIDUAL, false},
                     {"head N=4096 K=2560 store+norm (fast_output / live LM head)", 4096, 2560, EPI_STORE, true}};
+  printf("switches: FMI_GEMV_NOHOLD=%s FMI_GEMV_LATE_EPI=%s\n", getenv("FMI_GEMV_NOHOLD") ? getenv("FMI_GEMV_NOHOLD") : "0",
+         getenv("FMI_GEMV_LATE_EPI") ? getenv("FMI_GEMV_LATE_EPI") : "0");
   for (const Shape& sh : shapes) {
-    if (quick && sh.N != 19456 && !(sh.N == 2560 && sh.K == 4096)) continue;
     const double bytes = (double)sh.N * sh.K * 2;
+    const size_t elems = (size_t)sh.N * sh.K;
     const int nbuf = (int)(2.0e9 / bytes) + 1;
-    std::vector<bf16_t*> wbufs(nbuf);
-    for (auto& p : wbufs) { CK(hipMalloc((void**)&p, (size_t)bytes)); CK(hipMemset(p, 0x11, (size_t)bytes)); }
-    bf16_t *x, *nw, *res, *out;
-    CK(hipMalloc((void**)&x, (size_t)16 * sh.K * 2)); CK(hipMemset(x, 0x3c, (size_t)16 * sh.K * 2));
-    CK(hipMalloc((void**)&nw, (size_t)sh.K * 2)); CK(hipMemset(nw, 0x3c, (size_t)sh.K * 2));
-    CK(hipMalloc((void**)&res, (size_t)16 * sh.N * 2)); CK(hipMemset(res, 0, (size_t)16 * sh.N * 2));
-    CK(hipMalloc((void**)&out, (size_t)16 * sh.N * 2));
-    printf("%s  (%.1f MB, M=%d)\n", sh.name, bytes / 1e6, M);
-    // paired activation loads (the M <= 8 path) over pairs-in-flight x tiles, then the per-tile-load path (M > 8) of the shipped shapes
-    V(8, 1, 2, true); V(8, 2, 2, true); V(8, 1, 1, true); V(8, 2, 1, true); V(8, 4, 1, true); V(16, 1, 2, true); V(16, 2, 1, true);
-    // one chunk = the wave's whole k-slice in flight (K = 2560: 5 pairs per wave of 8, 10 per wave of 4; K = 4096: 8):
-    // a single exposed round trip per work-group instead of one per chunk (round-3 candidates)
-    V(8, 5, 2, true); V(8, 5, 1, true); V(4, 10, 1, true); V(4, 5, 2, true); V(8, 8, 1, true); V(8, 3, 2, true);
-    VX(8, 1, 2); VX(8, 2, 1);
-    { float us = run_shipped(sh, wbufs, x, nw, res, out, M, iters); printf("  shipped launcher (launch_linear_skinny) : %7.2f us  %6.0f GB/s\n", us, bytes / us * 1e-3); }
-    for (auto p : wbufs) hipFree(p);
-    hipFree(x); hipFree(nw); hipFree(res); hipFree(out);
+    std::vector<bf16_t*> w16(nbuf), wr;
+    bf16_t* rowmajor; CK(hipMalloc((void**)&rowmajor, elems * 2));
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, 0, rowmajor, elems, 7u, 0.05f);
+    for (auto& p : w16) {
+      CK(hipMalloc((void**)&p, elems * 2));
+      if (sh.epi == EPI_SILU) { launch_pack_weight(rowmajor, p, sh.N / 2, sh.K, 1, 0); launch_pack_weight(rowmajor + elems / 2, p, sh.N / 2, sh.K, 2, 0); }
+      else launch_pack_weight(rowmajor, p, sh.N, sh.K, 0, 0);
+    }
+    const bool rows = skinny_rows_supported(sh.N, sh.K, sh.epi, sh.norm);
+    const RowPlan plan = skinny_row_plan(sh.N, sh.K, sh.epi);
+    if (rows) {
+      wr.resize(nbuf);
+      for (int i = 0; i < nbuf; ++i) { CK(hipMalloc((void**)&wr[i], (size_t)plan.elems * 2)); launch_repack_rows(w16[i], wr[i], sh.N, sh.K, sh.epi, plan, 0); }
+    }
+    CK(hipDeviceSynchronize());
+    hipFree(rowmajor);
+    const int n_out = sh.epi == EPI_SILU ? sh.N / 2 : sh.N;
+    bf16_t *x, *nw, *res, *out, *out1;
+    CK(hipMalloc((void**)&x, (size_t)16 * sh.K * 2)); CK(hipMalloc((void**)&nw, (size_t)sh.K * 2));
+    CK(hipMalloc((void**)&res, (size_t)16 * n_out * 2)); CK(hipMalloc((void**)&out, (size_t)16 * n_out * 2)); CK(hipMalloc((void**)&out1, (size_t)16 * n_out * 2));
+    hipLaunchKernelGGL(fill_kernel, dim3((16 * sh.K + 255) / 256), dim3(256), 0, 0, x, (size_t)16 * sh.K, 11u, 1.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3((sh.K + 255) / 256), dim3(256), 0, 0, nw, (size_t)sh.K, 13u, 1.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3((16 * n_out + 255) / 256), dim3(256), 0, 0, res, (size_t)16 * n_out, 17u, 1.0f);
+    printf("%s  (%.1f MB%s)\n", sh.name, bytes / 1e6, rows ? ", row-balanced copy" : "");
+    LinearArgs a{};
+    a.x = x; a.ldx = sh.K; a.norm_w = sh.norm ? nw : nullptr; a.eps = 1e-6f; a.res = res; a.N = sh.N; a.K = sh.K; a.epi = sh.epi;
+    a.ldr = n_out; a.out = out; a.ldo = n_out;
+    for (int M : {1, 8, 12, 16}) {
+      a.M = M;
+      const float us = time_launches(a, w16, wr, iters);
+      printf("  M=%2d shipped launcher : %7.2f us  %6.0f GB/s\n", M, us, bytes / us * 1e-3);
+      fflush(stdout);
+    }
+    if (check) {  // row r of the M-row result == the M = 1 result of that row
+      std::vector<bf16_t> ref((size_t)16 * n_out), got((size_t)16 * n_out);
+      for (int r = 0; r < 16; ++r) {
+        LinearArgs b = a; b.M = 1; b.x = x + (size_t)r * sh.K; b.res = res + (size_t)r * n_out; b.out = out1 + (size_t)r * n_out;
+        b.wp = w16[0]; b.wr = rows ? wr[0] : nullptr;
+        launch_linear_skinny(b, 0);
+      }
+      CK(hipMemcpy(ref.data(), out1, ref.size() * 2, hipMemcpyDeviceToHost));
+      for (int M : {8, 12, 16}) {
+        LinearArgs b = a; b.M = M; b.wp = w16[0]; b.wr = rows ? wr[0] : nullptr;
+        CK(hipMemset(out, 0, (size_t)16 * n_out * 2));
+        launch_linear_skinny(b, 0);
+        CK(hipMemcpy(got.data(), out, got.size() * 2, hipMemcpyDeviceToHost));
+        const bool same = memcmp(ref.data(), got.data(), (size_t)M * n_out * 2) == 0;
+        printf("  M=%2d rows == their M=1 results: %s\n", M, same ? "yes (bit for bit)" : "NO");
+      }
+    }
+    for (auto p : w16) hipFree(p);
+    for (auto p : wr) hipFree(p);
+    hipFree(x); hipFree(nw); hipFree(res); hipFree(out); hipFree(out1);
   }
   return 0;
 }

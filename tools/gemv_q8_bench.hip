@@ -23,7 +23,7 @@ float run_variant(const Shape& sh, std::vector<void*>& wbufs, bf16_t* x, bf16_t*
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto go = [&](int i) {
     if (Q8) a.wq = (const int8_t*)wbufs[i % wbufs.size()]; else a.wp = (const bf16_t*)wbufs[i % wbufs.size()];
-    hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, true, true, Q8>), grid, block, 0, 0, a);
+    hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, 8, true, Q8>), grid, block, 0, 0, a);
   };
   for (int w = 0; w < 3; ++w) go(w);
   CK(hipDeviceSynchronize());

@@ -43,7 +43,7 @@ static float time_rows(const Shape& sh, Bufs& b, int M, int iters, bool check) {
   if (check) {
     CK(hipMemset(b.out, 0xff, (size_t)16 * n_out * 2));
     a.wp = b.wr[0];
-    hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, true, true, false, ROWS>), grid, block, 0, 0, a);
+    hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, 8, true, false, ROWS>), grid, block, 0, 0, a);
     CK(hipDeviceSynchronize());
     std::vector<bf16_t> got((size_t)M * n_out), want((size_t)M * n_out);
     CK(hipMemcpy(got.data(), b.out, got.size() * 2, hipMemcpyDeviceToHost));
@@ -53,10 +53,10 @@ static float time_rows(const Shape& sh, Bufs& b, int M, int iters, bool check) {
     if (bad) { printf("  !! W=%d UNR=%d TILES=%d ROWS=%d: %zu of %zu outputs differ from the 16-row kernel\n", WAVES, UNR, TILES, ROWS, bad, got.size()); return -2.f; }
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) { a.wp = b.wr[w % b.wr.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, true, true, false, ROWS>), grid, block, 0, 0, a); }
+  for (int w = 0; w < 3; ++w) { a.wp = b.wr[w % b.wr.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, 8, true, false, ROWS>), grid, block, 0, 0, a); }
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) { a.wp = b.wr[i % b.wr.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, true, true, false, ROWS>), grid, block, 0, 0, a); }
+  for (int i = 0; i < iters; ++i) { a.wp = b.wr[i % b.wr.size()]; hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI, NORM, UNR, TILES, 8, true, false, ROWS>), grid, block, 0, 0, a); }
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   return ms * 1e3f / iters;

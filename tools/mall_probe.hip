@@ -25,7 +25,7 @@ float gemv_time(const bf16_t* w, const bf16_t* warm, size_t bytes, int N, int K,
   for (int r = 0; r < reps; ++r) {
     hipLaunchKernelGGL(touch_kernel, dim3(2048), dim3(256), 0, 0, (const u32x4*)warm, bytes / 16, sink);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((linear_skinny_kernel<8, EPI, NORM, UNR, TILES, NT>), dim3(N / (16 * TILES)), dim3(512), 0, 0, a);
+    hipLaunchKernelGGL((linear_skinny_kernel<8, EPI, NORM, UNR, TILES, 8, NT>), dim3(N / (16 * TILES)), dim3(512), 0, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
   }

@@ -51,8 +51,12 @@ def main(path, n_frames, out_json=None):
           f"= {frame_bytes / (n_decode + 0.52 * n_prefill) / 1e9:.3f} GB per decode frame "
           f"(a prefill frame's tail counted as 0.52 frame: the fast chain and the heads of a frame)")
     if out_json:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from fish_speech_amd.build import decode_sources_sha
+
         with open(out_json, "w") as f:
-            json.dump({"bytes_per_decode_frame": round(frame_bytes / (n_decode + 0.52 * n_prefill)), "batch": 8,
+            json.dump({"decode_sources_sha": decode_sources_sha(), "bytes_per_decode_frame": round(frame_bytes / (n_decode + 0.52 * n_prefill)), "batch": 8,
                        "decode_frames_in_pass": n_decode, "prefill_frames_in_pass": n_prefill,
                        "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace over `bench.py --frames %d --steps 1 --warmup 0 "
                                  "--no-codec --no-extras --no-cpu-baseline` (tools/make_profiles.sh), summed over the decode-frame "
