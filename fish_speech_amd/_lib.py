@@ -75,6 +75,7 @@ _SIGS = {
     "fmi_dualar_set_trace": (C.c_int, [_P, _I, C.POINTER(_P)]),
     "fmi_dualar_set_graph": (C.c_int, [_P, _I]),
     "fmi_dualar_set_attn_impl": (C.c_int, [_P, _I]),
+    "fmi_dualar_set_fast_merge": (C.c_int, [_P, _I]),
     "fmi_dualar_set_attn_long_threshold": (C.c_int, [_P, _I]),
     "fmi_dualar_set_ignore_eos": (C.c_int, [_P, _I]),
     "fmi_dualar_last_decode_stats": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),

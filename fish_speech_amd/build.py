@@ -9,8 +9,9 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfishmi.so")
-SOURCES = ["common.cpp", "dualar_kernels.hip", "dualar.hip", "dac_kernels.hip", "dac.hip"]
-HEADERS = ["common.h", "dualar_kernels.h", "dac_kernels.h", os.path.join("..", "..", "include", "fishmi.h")]
+SOURCES = ["common.cpp", "dualar_kernels.hip", "dualar_gemm.hip", "dualar_attn.hip", "dualar_sample.hip", "dualar.hip",
+           "dac_kernels.hip", "dac.hip"]
+HEADERS = ["common.h", "dualar_kernels.h", "dualar_dev.h", "dac_kernels.h", os.path.join("..", "..", "include", "fishmi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -20,7 +21,8 @@ def decode_sources_sha() -> str:
     import hashlib
 
     h = hashlib.sha1()
-    for name in ("common.h", "dualar_kernels.h", "dualar_kernels.hip", "dualar.hip"):
+    for name in ("common.h", "dualar_kernels.h", "dualar_dev.h", "dualar_kernels.hip", "dualar_gemm.hip", "dualar_attn.hip",
+                 "dualar_sample.hip", "dualar.hip"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

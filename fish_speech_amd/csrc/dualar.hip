@@ -72,6 +72,10 @@ struct fmi_dualar {
   std::vector<std::vector<int>> slot_pages;
   Workspace ws;
   bf16_t *hn = nullptr, *hf = nullptr, *xl = nullptr, *xf = nullptr, *logits = nullptr, *flogits = nullptr, *ftrace = nullptr;
+  // fast positions 0 and 1 of a frame in one pass (tail): rows [0, B) = the hidden states, rows [B, 2B) = the
+  // embeddings of the slow token's codes; [2 max_batch][fast_dim]
+  bf16_t* x01 = nullptr;
+  bool merge01 = true;                 // FMI_NO_MERGE01=1: positions 0 and 1 as two passes (rounds 1-3; A/B runs)
   // fast_dim != dim (llama.py:665-668): packed fast_project_in weight [fast_dim][dim] + bias in the arena, and the
   // projected hidden rows [max_batch][fast_dim] fast step 0 runs on
   bf16_t *fpi_w = nullptr, *fpi_b = nullptr, *hfp = nullptr;
@@ -359,21 +363,38 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
   return FMI_OK;
 }
 
+// merge01 (tail): x holds 2 B rows -- rows [0, B) the B utterances at fast position 0, rows [B, 2B) the same utterances
+// at position 1 -- and ONE pass over the layer's weights serves both (forward_generate_fast twice, inference.py:148-166:
+// both inputs are known once the slow token is drawn, and position 1 attends only to itself and to position 0's K/V of
+// the same layer).  qkv_rows1 != nullptr: the position-1 q|k|v rows are already in ws.qkv rows [B, 2B) (the tabulated
+// first layer), only the position-0 rows go through the GEMV.  last_rows1: the layer's output feeds nothing at
+// position 0 (its logits are discarded), so wo / FFN run on the position-1 rows only.
 int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int pos, const int32_t* row_slot,
-               hipStream_t s, bool kv_only = false, const bf16_t* qkv_pre = nullptr) {
+               hipStream_t s, bool kv_only = false, const bf16_t* qkv_pre = nullptr, bool merge01 = false,
+               bool qkv_rows1 = false, bool last_rows1 = false) {
   const Dims& d = h->fast;
   Workspace& ws = h->ws;
+  const int M = merge01 ? 2 * B : B;
   if (!qkv_pre)
-    FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, B, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv, w.r_wqkv));
+    FMI_CHECK(linear(h, x, d.dim, w.wqkv, w.attn_norm, nullptr, 0, ws.qkv, d.qkv, qkv_rows1 ? B : M, d.qkv, d.dim, EPI_STORE, s, w.q_wqkv, w.s_wqkv, w.r_wqkv));
   FastAttnArgs a{};
   a.qkv = qkv_pre ? qkv_pre : ws.qkv; a.out = ws.ao; a.kc = h->fkc[layer]; a.vc = h->fvc[layer];
   a.qnw = h->cfg.fast_attention_qk_norm ? w.q_norm : nullptr;
   a.knw = h->cfg.fast_attention_qk_norm ? w.k_norm : nullptr;
   a.rope = h->fast_rope; a.row_slot = row_slot; a.B = B; a.H = d.H; a.KVH = d.KVH; a.D = d.D;
-  a.ncb = h->cfg.num_codebooks; a.pos = pos; a.eps = h->cfg.norm_eps;
+  a.ncb = h->cfg.num_codebooks; a.pos = pos; a.eps = h->cfg.norm_eps; a.merge = merge01 ? 1 : 0;
   FMI_CHECK(launch_fast_attn(a, s));
   h->launches += 1;
   if (kv_only) return FMI_OK;  // only this layer's K/V at `pos` were needed
+  if (merge01) {
+    const int r0 = last_rows1 ? B : 0, m = M - r0;
+    bf16_t* xr = x + (int64_t)r0 * d.dim;
+    const bf16_t* ao = ws.ao + (int64_t)r0 * d.H * d.D;
+    FMI_CHECK(linear(h, ao, d.H * d.D, w.wo, nullptr, xr, d.dim, xr, d.dim, m, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo, w.r_wo));
+    FMI_CHECK(linear(h, xr, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, m, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
+    FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, xr, d.dim, xr, d.dim, m, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2, w.r_w2));
+    return FMI_OK;
+  }
   FMI_CHECK(linear(h, ws.ao, d.H * d.D, w.wo, nullptr, x, d.dim, x, d.dim, B, d.dim, d.H * d.D, EPI_RESIDUAL, s, w.q_wo, w.s_wo, w.r_wo));
   FMI_CHECK(linear(h, x, d.dim, w.w13, w.ffn_norm, nullptr, 0, ws.act, d.ffn, B, 2 * d.ffn, d.dim, EPI_SILU, s, w.q_w13, w.s_w13));
   FMI_CHECK(linear(h, ws.act, d.ffn, w.w2, nullptr, x, d.dim, x, d.dim, B, d.dim, d.ffn, EPI_RESIDUAL, s, w.q_w2, w.s_w2, w.r_w2));
@@ -384,11 +405,11 @@ int block_fast(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int B, int 
 // final norm, restricted tied head, constrained sampling + RAS, the fast-AR chain
 // (decode_one_token_ar, inference.py:108-181).
 // final norm + restricted tied head (llama.py:450-457): hn = normed hidden, logits over the live rows
-int tail_head(fmi_dualar* h, const bf16_t* xl, int B, hipStream_t s) {
+int tail_head(fmi_dualar* h, const bf16_t* xl, int B, hipStream_t s, bf16_t* hf_out = nullptr) {
   const fmi_dualar_config& c = h->cfg;
   const int dim = c.dim;
   // hn = normed hidden (head input, parity tap); hf = its copy that fast step 0 transforms in place
-  FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s, h->hf));
+  FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s, hf_out ? hf_out : h->hf));
   h->launches += 1;
   return linear(h, h->hn, dim, h->head_live, nullptr, nullptr, 0, h->logits, h->n_live_pad, B, h->n_live_pad, dim,
                 EPI_STORE, s);
@@ -404,33 +425,48 @@ int project_fast_in(fmi_dualar* h, const bf16_t* hid, bf16_t* out, int B, hipStr
 int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStream_t s) {
   const fmi_dualar_config& c = h->cfg;
   const int dim = c.dim;
-  FMI_CHECK(tail_head(h, xl, B, s));
+  // positions 0 and 1 of the fast transformer in one pass over its weights (block_fast: merge01): 2 B <= 16 rows of
+  // the decode GEMV; a row's bits do not depend on the rows it travels with, so nothing changes but the traffic
+  // (-0.6 GB per frame at the S2 shape) and the launch count (-16)
+  const bool merge = h->merge01 && !h->fpi_w && !c.weight_int8 && 2 * B <= 16 && c.num_codebooks >= 2 && c.fast_dim == c.dim &&
+                     h->ws.rows >= 2 * B;
+  bf16_t* const x0 = merge ? h->x01 : h->hf;                                   // position-0 rows
+  bf16_t* const xf = merge ? h->x01 + (int64_t)B * c.fast_dim : h->xf;         // rows of positions >= 1
+  FMI_CHECK(tail_head(h, xl, B, s, x0));
   SampleArgs sa{};
   sa.logits = h->logits; sa.B = B; sa.n = h->n_live; sa.ld = h->n_live_pad; sa.ids = h->live_ids;
   sa.row_slot = row_slot; sa.st = h->st; sa.mode = 0; sa.cb = 0; sa.sem_begin = c.semantic_begin_id;
   sa.sem_end = c.semantic_end_id; sa.im_end = h->ignore_eos ? -1 : c.im_end_id; sa.cbs = c.codebook_size; sa.fast_emb = h->fast_emb;
-  sa.xf = h->xf; sa.fdim = c.fast_dim; sa.small_k = h->max_top_k <= 64;
+  sa.xf = xf; sa.fdim = c.fast_dim; sa.small_k = h->max_top_k <= 64;
   const bool tab = h->qkv0_tab != nullptr && !h->trace;
-  sa.qkv0_tab = tab ? h->qkv0_tab : nullptr; sa.qkv0_out = h->qkv0_pre; sa.qkv0_dim = h->fast.qkv;
+  sa.qkv0_tab = tab ? h->qkv0_tab : nullptr; sa.qkv0_dim = h->fast.qkv;
+  // merged pass: the tabulated q|k|v rows of the slow token's codes land where the GEMV would have put them
+  sa.qkv0_out = merge ? h->ws.qkv + (int64_t)B * h->fast.qkv : h->qkv0_pre;
   FMI_CHECK(launch_sample(sa, s));
   h->launches += 1;
+  sa.qkv0_out = h->qkv0_pre;
   // fast step 0 on the hidden state; its logits are discarded (inference.py:148-149)
-  bf16_t* f0 = h->hf;
+  bf16_t* f0 = x0;
   if (h->fpi_w) {        // fast_dim != dim: step 0 runs on the projected hidden rows
     FMI_CHECK(project_fast_in(h, c.norm_fastlayer_input ? h->hn : xl, h->hfp, B, s));
     f0 = h->hfp + (int64_t)h->max_batch * c.fast_dim;   // step 0 transforms its input in place: keep the tap
     FMI_CHECK_HIP(hipMemcpyAsync(f0, h->hfp, (size_t)B * c.fast_dim * 2, hipMemcpyDeviceToDevice, s));
   } else if (!c.norm_fastlayer_input) {
-    FMI_CHECK_HIP(hipMemcpyAsync(h->hf, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
+    FMI_CHECK_HIP(hipMemcpyAsync(x0, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
   }
   // Fast step 0 exists only to put the hidden state's K/V into slot 0 of every fast layer: its logits are
   // discarded (inference.py:148-149), so the last layer's wo / FFN output feeds nothing and is skipped.
-  for (int i = 0; i < c.n_fast_layer; ++i)
-    FMI_CHECK(block_fast(h, h->FL[i], i, f0, B, 0, row_slot, s, i == c.n_fast_layer - 1));
-  for (int cb = 1; cb < c.num_codebooks; ++cb) {
+  if (!merge)
     for (int i = 0; i < c.n_fast_layer; ++i)
-      FMI_CHECK(block_fast(h, h->FL[i], i, h->xf, B, cb, row_slot, s, false, (i == 0 && tab) ? h->qkv0_pre : nullptr));
-    FMI_CHECK(linear(h, h->xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, B,
+      FMI_CHECK(block_fast(h, h->FL[i], i, f0, B, 0, row_slot, s, i == c.n_fast_layer - 1));
+  for (int cb = 1; cb < c.num_codebooks; ++cb) {
+    for (int i = 0; i < c.n_fast_layer; ++i) {
+      if (merge && cb == 1)
+        FMI_CHECK(block_fast(h, h->FL[i], i, h->x01, B, 0, row_slot, s, false, nullptr, true, i == 0 && tab, i == c.n_fast_layer - 1));
+      else
+        FMI_CHECK(block_fast(h, h->FL[i], i, xf, B, cb, row_slot, s, false, (i == 0 && tab) ? h->qkv0_pre : nullptr));
+    }
+    FMI_CHECK(linear(h, xf, c.fast_dim, h->fast_out, h->fast_norm, nullptr, 0, h->flogits, c.codebook_size, B,
                      c.codebook_size, c.fast_dim, EPI_STORE, s, h->q_fast_out, h->s_fast_out));
     if (h->trace) {
       FMI_CHECK_HIP(hipMemcpy2DAsync(h->ftrace + (int64_t)cb * c.codebook_size,
@@ -634,7 +670,7 @@ void fmi_dualar_destroy(fmi_dualar* h) {
   void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
                   h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
                   h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging, h->staging2,
-                  h->qkv0_tab, h->qkv0_pre, h->attn_part, h->hfp};
+                  h->qkv0_tab, h->qkv0_pre, h->attn_part, h->hfp, h->x01};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (void* p : h->row_copies) hipFree(p);
@@ -895,6 +931,11 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
   FMI_CHECK(dev_alloc(&h->hf, (int64_t)max_batch * c.dim));
   if (c.fast_dim != c.dim) FMI_CHECK(dev_alloc(&h->hfp, (int64_t)2 * max_batch * c.fast_dim));   // parity tap | step-0 work copy
   FMI_CHECK(dev_alloc(&h->xf, (int64_t)max_batch * c.fast_dim));
+  FMI_CHECK(dev_alloc(&h->x01, (int64_t)2 * max_batch * c.fast_dim));
+  {
+    static const bool off = []() { const char* e = getenv("FMI_NO_MERGE01"); return e && atoi(e) != 0; }();
+    h->merge01 = !off;
+  }
   FMI_CHECK(dev_alloc(&h->logits, (int64_t)max_batch * h->n_live_pad));
   FMI_CHECK(dev_alloc(&h->flogits, (int64_t)max_batch * c.codebook_size));
   FMI_CHECK(dev_alloc(&h->ftrace, (int64_t)max_batch * c.num_codebooks * c.codebook_size));
@@ -910,7 +951,7 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
     if (!attn_decode_long_supported(s.H, s.KVH, s.D)) h->attn_long_thr = 0;
     if (h->attn_long_thr > 0) FMI_CHECK(dev_alloc(&h->attn_part, attn_decode_long_part_floats(max_batch, s.H, s.D)));
   }
-  return ensure_rows(h, max_batch);
+  return ensure_rows(h, std::max(max_batch, std::min(16, 2 * max_batch)));   // the merged fast pass runs 2 B <= 16 rows
 }
 
 int fmi_dualar_release(fmi_dualar* h, int slot) {
@@ -947,7 +988,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
     ~TiledGuard() { h->force_tiled = false; }
   } guard{h};
   h->force_tiled = pos0 != nullptr && any_long;
-  FMI_CHECK(ensure_rows(h, std::max(rows, h->max_batch)));
+  FMI_CHECK(ensure_rows(h, std::max(rows, std::max(h->max_batch, std::min(16, 2 * h->max_batch)))));
   std::vector<int32_t> row_slot(rows), row_pos(rows), last(n), slots(n);
   std::vector<int4> tiles;
   int r = 0;
@@ -1288,6 +1329,14 @@ int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl) {
   FMI_REQUIRE(h, "null handle");
   FMI_REQUIRE(impl == 0 || impl == 1, "attn impl must be 0 (VALU) or 1 (MFMA)");
   h->attn_impl = impl;
+  return FMI_OK;
+}
+
+int fmi_dualar_set_fast_merge(fmi_dualar* h, int enable) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  drop_graphs(h);
+  h->merge01 = enable != 0;
   return FMI_OK;
 }
 

@@ -145,6 +145,7 @@ struct FastAttnArgs {
   const int32_t* row_slot;
   int B, H, KVH, D, ncb, pos;
   float eps;
+  int merge;           // 1: rows [0, B) are position 0 and rows [B, 2B) position 1 of the same B utterances (pos ignored)
 };
 int launch_fast_attn(const FastAttnArgs& a, hipStream_t s);
 

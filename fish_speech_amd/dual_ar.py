@@ -541,6 +541,10 @@ class MiDualAR:
         """Prefill attention kernel: 1 = MFMA flash attention (default), 0 = VALU kernel (A/B parity runs)."""
         check(self.lib.fmi_dualar_set_attn_impl(self._h, int(impl)))
 
+    def set_fast_merge(self, enable: bool):
+        """Fast positions 0 and 1 of a frame in one pass over the fast weights (default) or in two (A/B parity runs)."""
+        check(self.lib.fmi_dualar_set_fast_merge(self._h, int(bool(enable))))
+
     def set_attn_long_threshold(self, threshold: int):
         """Decode attention: rows at or beyond this position use the MFMA kernel + merge, the others the fused VALU
         kernel (default 1024; 0 = VALU for every row).  Call after setup_caches."""

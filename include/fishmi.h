@@ -177,6 +177,11 @@ int fmi_dualar_set_graph(fmi_dualar* h, int enable);
 /* Prefill attention implementation (F.scaled_dot_product_attention, llama.py:928-934): 1 = MFMA flash attention with
  * LDS-staged K/V tiles (default), 0 = the VALU kernel of round 1 (kept for A/B parity runs). */
 int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl);
+/* Fast transformer positions 0 and 1 of a frame (the two forward_generate_fast calls of inference.py:148-149 and :166,
+ * whose inputs are both known once the slow token is drawn): 1 = one pass over the fast weights with 2 x batch rows
+ * (default when 2 x batch <= 16, bf16 weights, fast_dim == dim), 0 = two passes (rounds 1-3; kept for A/B parity runs).
+ * Results are bit-identical either way. */
+int fmi_dualar_set_fast_merge(fmi_dualar* h, int enable);
 /* Decode attention (the per-frame step of llama.py:910-934 over the KV cache): rows whose position is >= threshold run
  * on the MFMA kernel (all query heads of a kv head in one work-group, key ranges split over work-groups, partial
  * softmax states merged), the others on the fused VALU kernel; which one depends only on the row's own position.

@@ -22,7 +22,10 @@ from oracle import dual_ar as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = [c for c in ("s2_plain", "s2_clone", "s2_sampled") if os.path.exists(os.path.join(GOLDEN, f"dualar_{c}.npz"))]
+# s2_plain215 (round 4): the benchmark's full 215 frames (context 200 -> 415, all 7 KV pages of a 512-position slot);
+# s2_sampled2 (round 4): sampled decisions that leave the top-1 candidate at the BASELINE width
+CASES = [c for c in ("s2_plain", "s2_clone", "s2_sampled", "s2_plain215", "s2_sampled2")
+         if os.path.exists(os.path.join(GOLDEN, f"dualar_{c}.npz"))]
 
 
 def _load(name):
@@ -73,6 +76,7 @@ def test_s2_full_sequence_equals_the_reference(case):
               top_p=float(z["top_p"]), top_k=int(z["top_k"]), seed=int(z["uniform_seed"]))
     assert z["prompt"].shape[1] == 200 and want.shape[1] - 200 >= 64
     model.set_graph(True)
+    model.set_fast_merge(True)
     got = generate(model=model, **kw).numpy()
     assert got.shape == want.shape, (got.shape, want.shape)
     bad = np.argwhere(got != want)
@@ -81,28 +85,63 @@ def test_s2_full_sequence_equals_the_reference(case):
     got2 = generate(model=model, poll_every=1, **kw).numpy()
     model.set_graph(True)
     assert np.array_equal(got2, want), f"{case}: eager path differs"
+    # fast positions 0 and 1 as two passes over the fast weights (rounds 1-3) instead of one: the same tokens
+    model.set_fast_merge(False)
+    got3 = generate(model=model, **kw).numpy()
+    model.set_fast_merge(True)
+    assert np.array_equal(got3, want), f"{case}: two-pass fast positions 0 / 1 differ"
     print(case, "full sequence equal;", str(z["note"]))
 
 
 def test_s2_golden_utterances_inside_a_ragged_batch_of_8():
-    """The same utterances as rows 2 and 5 of a ragged batch of 8 (config 4's mixed lengths: batch-8 GEMV variants,
-    eight slots' pages interleaved in the pool): still the reference's token matrix, for both."""
+    """A ragged batch of 8 (config 4's mixed lengths: batch-8 GEMV variants, eight slots' pages interleaved in the
+    pool) in which EVERY row is the unmodified reference's: rows 2 and 5 are s2_plain / s2_clone, the other six come
+    from dualar_s2_ragged.npz (round 4; oracle/gen_golden_s2.py s2_ragged: prompts of 57 / 333 / 131 / 64 / 400 / 90
+    tokens, every decision >= 16 bf16 steps of margin).  All eight token matrices must be equal."""
     from fish_speech_amd.dual_ar import generate_batch
 
     zp, skw = _load("s2_plain")
     zc, _ = _load("s2_clone")
+    zr, skw_r = _load("s2_ragged")
+    assert skw_r == skw
     cfg, model, _ = _model(skw)
     lens = [57, 333, 200, 131, 64, 200, 400, 90]
-    prompts, seeds = [], []
-    for i, T in enumerate(lens):
-        prompts.append(O.make_prompt(cfg, T, seed=300 + i, n_semantic=(T // 3 if i % 2 else 0)))
-        seeds.append(700 + i)
-    prompts[2], seeds[2] = torch.from_numpy(zp["prompt"]), int(zp["uniform_seed"])
-    prompts[5], seeds[5] = torch.from_numpy(zc["prompt"]), int(zc["uniform_seed"])
+    prompts, seeds, want = [None] * 8, [None] * 8, [None] * 8
+    prompts[2], seeds[2], want[2] = torch.from_numpy(zp["prompt"]), int(zp["uniform_seed"]), zp["tokens"]
+    prompts[5], seeds[5], want[5] = torch.from_numpy(zc["prompt"]), int(zc["uniform_seed"]), zc["tokens"]
+    for row in zr["rows"].tolist():
+        prompts[row], seeds[row] = torch.from_numpy(zr[f"prompt_{row}"]), int(zr["uniform_seed_base"]) + row
+        want[row] = zr[f"tokens_{row}"]
+    assert [p.shape[1] for p in prompts] == lens
     out = generate_batch(model=model, prompts=prompts, max_new_tokens=64, temperature=0.7, top_p=0.7, top_k=1,
                          seeds=seeds, stop_on_im_end=False)
-    assert np.array_equal(out[2].numpy(), zp["tokens"])
-    assert np.array_equal(out[5].numpy(), zc["tokens"])
+    for row in range(8):
+        assert np.array_equal(out[row].numpy(), want[row]), f"row {row} (T = {lens[row]}) differs from the reference"
+
+
+def test_s2_int8_full_sequence_equals_the_reference_int8_run():
+    """The S2-width int8 fixture (round 4; what `bench.py --int8` rests on): the s2_plain utterance on the same hash
+    weights quantised by the reference's own WeightOnlyInt8QuantHandler (tools/llama/quantize.py:186-229) and generated
+    by the unmodified reference through its int8 Linear (llama.py:529-534).  The HIP path loaded from the int8
+    checkpoint (int8 tiles streamed by the decode GEMVs, scales in the epilogues) returns the same (11, 264) matrix."""
+    from fish_speech_amd.dual_ar import DualARConfig, MiDualAR, generate
+
+    z, skw = _load("s2_int8")
+    ocfg = O.s2_pro_shaped_config(max_seq_len=512)
+    state = O.make_peaky_state_hash(ocfg, device=DEV, **skw)
+    q = O.quantize_state_int8(ocfg, state)
+    del state
+    mcfg = DualARConfig.from_any(ocfg)
+    mcfg.weight_int8 = True
+    model = MiDualAR(mcfg, device=DEV, im_end_id=ocfg.im_end_id).load_state_dict(q)
+    del q
+    model.setup_caches(2, 512)
+    got = generate(model=model, prompt=torch.from_numpy(z["prompt"]), max_new_tokens=int(z["max_new"]), temperature=0.7,
+                   top_p=0.7, top_k=1, seed=int(z["uniform_seed"])).numpy()
+    want = z["tokens"]
+    bad = np.argwhere(got != want) if got.shape == want.shape else None
+    assert got.shape == want.shape and len(bad) == 0, f"first mismatch at {None if bad is None else bad[0].tolist()}"
+    print("s2_int8 full sequence equal;", str(z["note"]))
 
 
 def test_s2_oracle_on_this_box_equals_the_fixture_and_bounds_the_taps():

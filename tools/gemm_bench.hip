@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../fish_speech_amd/csrc/dualar_kernels.hip"
+#include "../fish_speech_amd/csrc/dualar_gemm.hip"
 
 using namespace fmi;
 

@@ -2,7 +2,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "../fish_speech_amd/csrc/dualar_kernels.hip"
+#include "../fish_speech_amd/csrc/dualar_sample.hip"
 using namespace fmi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 int main() {
