@@ -375,6 +375,29 @@ def run_config4(model, codec, cfg, rank, world, dist, device):
             "rank_imbalance_max_over_mean": round(dt_max / dt_mean, 4)}
 
 
+def run_batch16(model, codec, cfg, device):
+    """The bench step with 16 utterances per GPU instead of 8 (NOT the headline, BASELINE.json
+    quotes batch 8): the decode GEMVs take their rows in two sets of 8 (linear_skinny_kernel<..., XR = 16>), one pass
+    over the weights serves all 16.  Same prompts shape, same sampler, codec decode of all 16 inside the timed step."""
+    model.setup_caches(16, cfg.max_seq_len)
+    model.set_ignore_eos(True)
+    prompts = make_prompts(cfg, 16, 5000)
+    seeds = [9000 + i for i in range(16)]
+    run_step(model, codec, prompts, seeds, device)
+    _sync(device)
+    t0 = time.perf_counter()
+    codes, _ = run_step(model, None, prompts, seeds, device)
+    ms, launches = model.last_decode_stats()
+    codec.from_indices(codes)
+    _sync(device)
+    dt = time.perf_counter() - t0
+    model.setup_caches(BATCH, cfg.max_seq_len)
+    model.set_ignore_eos(True)
+    return {"batch_per_gpu": 16, "audio_sec_per_s": round(16 * N_FRAMES * FRAME_LEN / SAMPLE_RATE / dt, 2),
+            "ms_per_step": round(dt * 1e3, 1), "decode_frame_avg_ms": round(ms / (N_FRAMES - 1), 4),
+            "launches_per_frame": launches, "note": "codec decode of the 16 utterances inside the step; not the headline"}
+
+
 def run_config1(model, codec, cfg, device):
     """Config 1 (BASELINE configs[1]): one utterance, greedy, 200-token prompt -> 215 frames + codec decode."""
     from fish_speech_amd.dual_ar import generate_batch_device
@@ -661,6 +684,7 @@ def main():
             extras["config1_batch1_greedy"] = run_config1(model, codec, cfg, device)
             extras["config4_streaming"] = run_config5(model, codec, cfg, device)
             extras["config4_streaming_staggered_arrivals"] = run_config5_staggered(model, codec, cfg)
+            extras["batch16"] = run_batch16(model, codec, cfg, device)
         out["other_configs"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, state, codec_state)

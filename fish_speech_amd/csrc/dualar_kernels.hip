@@ -406,7 +406,7 @@ constexpr int SKINNY_XH = 5;   // k-tile pairs of activations a wave can hold (K
 // Epilogue operands that do not depend on the products (residual, int8 row scale, bias) are requested at the top of the
 // kernel: loaded after the last barrier they were one more dependent L2 miss at the tail of every wo / w2 launch.
 template <int WAVES, int EPI, bool NORM, int UNR, int TILES, int XR, bool NT = true, bool Q8 = false, int ROWS = 16, int XH = 0>
-__global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR == 1) ? (XR == 8 ? 6 : 4) : 1) void linear_skinny_kernel(LinearArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR == 1) ? ((XR == 8 || XH == 0) ? 6 : 4) : 1) void linear_skinny_kernel(LinearArgs a) {
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
   static_assert(XR == 8 || XR == 16, "activation row sets of 8");
   static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || (!Q8 && EPI != EPI_SILU)), "row-balanced tiles: bf16, no SwiGLU");
@@ -734,7 +734,16 @@ static bool skinny_late_epi() {   // FMI_GEMV_LATE_EPI=1: residual / scale / bia
   static const bool on = []() { const char* e = getenv("FMI_GEMV_LATE_EPI"); return e && atoi(e) != 0; }();
   return on;
 }
+// Rows 9-16 (XR = 16): the held fragments of TWO row sets (40 registers) push the SwiGLU variant to 128 registers + spills
+// at two work-groups per CU, so its 608 work-groups need a second, nearly empty round (31.7 us against 20.4 at M = 8);
+// with the round-3 prologue it fits 80 registers = three work-groups per CU = one round.  FMI_GEMV_WIDE_HOLD: 0 = no wide
+// variant holds, 1 (default) = all but SwiGLU hold, 2 = all hold (A/B runs).
+static int skinny_wide_hold() {
+  static const int v = []() { const char* e = getenv("FMI_GEMV_WIDE_HOLD"); return e ? atoi(e) : 1; }();
+  return v;
+}
 static bool skinny_can_hold(const LinearArgs& a, int waves) {
+  if (a.M > 8 && (skinny_wide_hold() == 0 || (skinny_wide_hold() == 1 && a.epi == EPI_SILU))) return false;
   return a.norm_w != nullptr && (a.K % 64) == 0 && a.K / 64 == SKINNY_XH * waves && skinny_hold_enabled();
 }
 
