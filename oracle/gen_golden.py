@@ -154,6 +154,11 @@ PEAKY_CASES = {
     "tiny_peaky_eos": ({}, dict(seed=8, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5, eos_code=17), (24, 8, 2), 96,
                        (0.7, 0.7, 1), 1234),
     "mid_peaky": (_MID, dict(seed=93, emb_gain=2.5, slow_gain=3.0, fast_gain=2.5), (40, 12, 3), 48, (0.7, 0.7, 1), 1234),
+    # round 4 (VERDICT r03 weak #1d): a 1010-token prompt, so that the free-running run crosses position 1024 -- the
+    # threshold at which decode attention moves from the fused VALU kernel to the MFMA split-K kernel + merge -- in
+    # frame 14 of 40 (seed / gains from a search like search_golden.search_greedy: min margin 10 bf16 steps)
+    "mid_long": (dict(_MID, max_seq_len=2048), dict(seed=93, emb_gain=3.0, slow_gain=4.0, fast_gain=6.0), (1010, 300, 4), 40,
+                 (0.7, 0.7, 1), 1234),
     # the same model quantised by the reference's own WeightOnlyInt8QuantHandler (name suffix _int8)
     "tiny_peaky_int8": ({}, dict(seed=1, emb_gain=1.5, slow_gain=2.0, fast_gain=1.5), (24, 8, 1), 48, (0.7, 0.7, 1), 1234),
     # fast_dim != dim: the reference's fast_project_in Linear(dim, fast_dim) with bias (llama.py:665-668,827)

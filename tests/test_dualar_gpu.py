@@ -288,7 +288,7 @@ def test_generate_free_running_vs_reference_golden(case):
     assert np.array_equal(got[:, :T], want[:, :T])
 
 
-@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled", "tiny_projin"])
+@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled", "tiny_projin", "mid_long"])
 def test_generate_full_sequence_equals_reference_on_well_conditioned_fixtures(case):
     """STRICT index parity: prefill + hipGraph decode loop, free-running, against the token
     sequence the UNMODIFIED reference's generate() (inference.py:243-359) wrote for the well-conditioned fixtures
@@ -312,9 +312,21 @@ def test_generate_full_sequence_equals_reference_on_well_conditioned_fixtures(ca
                     temperature=float(z["temperature"]), top_p=float(z["top_p"]), top_k=int(z["top_k"]),
                     seed=int(z["uniform_seed"]), poll_every=1).numpy()
     assert np.array_equal(got2, want)
+    if case == "mid_long":
+        # round 4: a 1010-token prompt + 40 frames -- frames 14.. sit at positions >= 1024, where decode attention runs on
+        # attn_decode_mfma_kernel + attn_decode_merge_kernel; the reference's indices must come out of BOTH regimes
+        # (threshold 0 = the fused VALU kernel for every row)
+        assert z["prompt"].shape[1] < 1024 < want.shape[1]
+        model.set_graph(True)
+        model.set_attn_long_threshold(0)
+        got3 = generate(model=model, prompt=torch.from_numpy(z["prompt"]), max_new_tokens=int(z["max_new"]),
+                        temperature=float(z["temperature"]), top_p=float(z["top_p"]), top_k=int(z["top_k"]),
+                        seed=int(z["uniform_seed"])).numpy()
+        model.set_attn_long_threshold(1024)
+        assert np.array_equal(got3, want)
 
 
-@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_projin"])
+@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_projin", "mid_long"])
 def test_teacher_forced_exact_decisions_on_well_conditioned_fixtures(case):
     """Teacher-forced through the decode_one_token seam with the reference's history: taps within the bf16 noise
     bound AND every single decision equal to the reference's (exact == decisions)."""

@@ -43,7 +43,7 @@ def test_oracle_free_running_vs_reference_golden(case, mode, top_k):
     assert np.array_equal(y[:, : T + k], want[:, : T + k])
 
 
-@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled", "tiny_peaky_int8"])
+@pytest.mark.parametrize("case", ["tiny_peaky", "tiny_peaky_eos", "mid_peaky", "tiny_sampled", "tiny_peaky_int8", "mid_long"])
 def test_well_conditioned_fixtures_full_sequence_and_margins(case):
     """The well-conditioned fixtures (oracle.make_peaky_state; written by the unmodified reference's generate()):
     every decision of the reference run has >= 8 bf16 steps of margin (greedy) -- re-derived here from the stored
@@ -58,11 +58,13 @@ def test_well_conditioned_fixtures_full_sequence_and_margins(case):
     T = z["prompt"].shape[1]
     n = want.shape[1] - T
     top_k = int(z["top_k"])
-    assert n >= 40
+    assert n >= 40 or case == "mid_long"
     if top_k == 1:
         m = O.greedy_frame_margins(cfg, bf16_from_u16(z["slow_logits_live"]), bf16_from_u16(z["fast_logits"]))
         assert float(m.min()) >= 8.0 and O.robust_prefix(m, 8.0) == n
         assert np.array_equal(m.numpy(), z["greedy_margins_ulps"])
+    if case == "mid_long":   # a 1010-token prompt: the margins above are the CPU check; the oracle's free run equalled the
+        return               # reference's when the fixture was written (oracle/gen_golden.py asserts it) -- minutes of CPU here
     y = O.generate(O.DualAROracle(cfg, state), torch.from_numpy(z["prompt"]), int(z["max_new"]), float(z["temperature"]),
                    float(z["top_p"]), top_k, uniform_fn=O.FmiUniform(int(z["uniform_seed"]), 0)).numpy()
     assert y.shape == want.shape and np.array_equal(y, want)
