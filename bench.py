@@ -330,13 +330,15 @@ def mixed_length_workload(cfg, n_utts, seed=2024):
     return prompts, frames
 
 
-def run_config4(model, codec, cfg, rank, world, dist, device):
-    """Config 4: a global queue of 8 x world mixed-length utterances, LPT-packed over the ranks by expected frames
-    (scheduler.partition_for_ranks -- no data-path collective), each rank running its share through continuous
-    batching (8 slots, finished slots refilled) and decoding every utterance's codes with the codec."""
+def run_config4(model, codec, cfg, rank, world, dist, device, per_gpu=BATCH):
+    """Config 4: a global queue of per_gpu x world mixed-length utterances (BASELINE: 8 per GPU = batch 64 over 8 GPUs),
+    LPT-packed over the ranks by expected frames (scheduler.partition_for_ranks -- no data-path collective), each rank
+    running its share through continuous batching (8 slots, finished slots refilled) and decoding its utterances' codes
+    with the codec in ragged batches (MiDAC.from_indices_ragged).  per_gpu = 16: two utterances per slot, so the slots
+    refill (with 8 per GPU the loop runs the longest utterance's frames at a falling occupancy whatever the scheduler)."""
     from fish_speech_amd.scheduler import generate_queue, lpt_order, partition_for_ranks
 
-    prompts, frames = mixed_length_workload(cfg, BATCH * world)
+    prompts, frames = mixed_length_workload(cfg, per_gpu * world)
     mine = partition_for_ranks([f + 0.1 * p.shape[1] for p, f in zip(prompts, frames)], world)[rank]
     ps, fr = [prompts[i] for i in mine], [frames[i] for i in mine]
     seeds = [9000 + i for i in mine]
@@ -345,12 +347,14 @@ def run_config4(model, codec, cfg, rank, world, dist, device):
         res = generate_queue(model=model, prompts=ps, max_new_tokens=fr, max_batch=BATCH, seeds=seeds,
                              order=lpt_order(fr), temperature=0.7, top_p=0.7, top_k=30)
         n = 0
+        todo = []
         for r, p, f in zip(res, ps, fr):
-            codes = r[1:, p.shape[1]:].to(device).unsqueeze(0).contiguous()
+            codes = r[1:, p.shape[1]:].to(device).contiguous()
             assert codes.shape[-1] == f
-            if codec is not None:
-                codec.from_indices(codes)
+            todo.append(codes)
             n += f
+        if codec is not None:   # ragged batched decode: groups of up to 8 utterances of similar length per call
+            codec.from_indices_ragged(todo)
         _sync(device)
         return n
 
@@ -368,8 +372,8 @@ def run_config4(model, codec, cfg, rank, world, dist, device):
         dt_max, dt_mean, total = float(mx[0]), float(t[1]) / world, float(t[2])
     else:
         dt_max, dt_mean, total = dt, dt, float(n_frames)
-    return {"workload": f"configs[3]: {BATCH * world} mixed-length utterances (T~U[50,400], frames~U[100,430]) over "
-                        f"{world} GPU(s), LPT-partitioned, continuous batching with {BATCH} slots + per-utterance codec decode",
+    return {"workload": f"configs[3]: {per_gpu * world} mixed-length utterances (T~U[50,400], frames~U[100,430]) over "
+                        f"{world} GPU(s), LPT-partitioned, continuous batching with {BATCH} slots + ragged batched codec decode",
             "audio_sec_per_s": round(total * FRAME_LEN / SAMPLE_RATE / dt_max, 2), "wall_s": round(dt_max, 3),
             "frames_total": int(total),
             "rank_imbalance_max_over_mean": round(dt_max / dt_mean, 4)}
@@ -379,8 +383,6 @@ def run_batch16(model, codec, cfg, device):
     """The bench step with 16 utterances per GPU instead of 8 (NOT the headline, BASELINE.json
     quotes batch 8): the decode GEMVs take their rows in two sets of 8 (linear_skinny_kernel<..., XR = 16>), one pass
     over the weights serves all 16.  Same prompts shape, same sampler, codec decode of all 16 inside the timed step."""
-    model.setup_caches(16, cfg.max_seq_len)
-    model.set_ignore_eos(True)
     prompts = make_prompts(cfg, 16, 5000)
     seeds = [9000 + i for i in range(16)]
     run_step(model, codec, prompts, seeds, device)
@@ -391,8 +393,6 @@ def run_batch16(model, codec, cfg, device):
     codec.from_indices(codes)
     _sync(device)
     dt = time.perf_counter() - t0
-    model.setup_caches(BATCH, cfg.max_seq_len)
-    model.set_ignore_eos(True)
     return {"batch_per_gpu": 16, "audio_sec_per_s": round(16 * N_FRAMES * FRAME_LEN / SAMPLE_RATE / dt, 2),
             "ms_per_step": round(dt * 1e3, 1), "decode_frame_avg_ms": round(ms / (N_FRAMES - 1), 4),
             "launches_per_frame": launches, "note": "codec decode of the 16 utterances inside the step; not the headline"}
@@ -587,7 +587,9 @@ def main():
         from fish_speech_amd.dist import broadcast_arena
 
         broadcast_arena(model, src=0)
-    model.setup_caches(BATCH, cfg.max_seq_len)   # 1024 positions per slot: covers config 3's 400 + 430
+    # 1024 positions per slot: covers config 3's 400 + 430.  Sixteen slots (the handle's caches are set up once): the timed
+    # region runs 8 utterances in 8 of them, other_configs.batch16 all sixteen
+    model.setup_caches(2 * BATCH, cfg.max_seq_len)
     model.set_ignore_eos(True)
     codec, codec_state = None, None
     if not args.no_codec:
@@ -679,7 +681,8 @@ def main():
         out["encode"] = measure_encode(codec, device)
     if not args.no_extras and N_FRAMES == 215:
         # untimed extras: the other single-node configurations of BASELINE.json, measured with the same objects
-        extras = {"config3_mixed_lengths": run_config4(model, codec, cfg, rank, world, dist, device)}
+        extras = {"config3_mixed_lengths": run_config4(model, codec, cfg, rank, world, dist, device),
+                  "config3_mixed_lengths_queue16": run_config4(model, codec, cfg, rank, world, dist, device, per_gpu=2 * BATCH)}
         if world == 1 and codec is not None:
             extras["config1_batch1_greedy"] = run_config1(model, codec, cfg, device)
             extras["config4_streaming"] = run_config5(model, codec, cfg, device)

@@ -14,7 +14,7 @@ import itertools
 import math
 import threading
 from dataclasses import dataclass
-from typing import Dict, Iterable, Optional, Tuple
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -419,6 +419,45 @@ class MiDAC:
                 pass
         self._keep = work
         return out.to(self.module_dtype) if self.module_dtype != torch.float32 else out
+
+    # ---- ragged batch decode (the server's batched decode, tools/server/model_utils.py:61-86, over utterances of
+    # DIFFERENT lengths): utterances are grouped `max_group` at a time in order of length, a group is padded at its END
+    # to the longest member and decoded by ONE from_indices call; every codec layer is causal (modded_dac.py:521-588,
+    # window mask 380-398) and a row's result does not depend on its batch, so each utterance's samples are bit-identical
+    # to decoding it alone.  `pad_waste` bounds the padded frames a group may carry (fraction of its real frames); a
+    # group is closed early when the next utterance would exceed it.
+    @torch.no_grad()
+    def from_indices_ragged(self, codes: Sequence[torch.Tensor], max_group: int = 8, pad_waste: float = 0.35) -> List[torch.Tensor]:
+        """codes[i]: (1+n_codebooks, T_i) or (1, 1+n_codebooks, T_i) integer.  Returns [(1, 1, T_i * frame_length)]."""
+        items = []
+        for i, c in enumerate(codes):
+            c = c[0] if c.ndim == 3 else c
+            if c.shape[0] != self.config.n_codebooks + 1:
+                raise ValueError(f"expected {self.config.n_codebooks + 1} codebooks, got {c.shape[0]}")
+            items.append((int(c.shape[1]), i, c))
+        out: List[Optional[torch.Tensor]] = [None] * len(items)
+        order = sorted((it for it in items if it[0] > 0), key=lambda it: -it[0])
+        fl = self.frame_length
+        g = 0
+        while g < len(order):
+            tmax, real, e = order[g][0], 0, g
+            while e < len(order) and e - g < max_group:
+                r = real + order[e][0]
+                if e > g and (e - g + 1) * tmax - r > pad_waste * r:
+                    break
+                real, e = r, e + 1
+            group = order[g:e]
+            batch = torch.zeros(len(group), self.config.n_codebooks + 1, tmax, dtype=torch.int64, device=self.device)
+            for j, (t, _, c) in enumerate(group):
+                batch[j, :, :t] = c.to(device=self.device, dtype=torch.int64)
+            wav = self.from_indices(batch)
+            for j, (t, i, _) in enumerate(group):
+                out[i] = wav[j:j + 1, :, : t * fl]
+            g = e
+        for t, i, _ in items:
+            if t == 0:
+                out[i] = torch.zeros(1, 1, 0, dtype=self.module_dtype, device=self.device)
+        return out  # type: ignore[return-value]
 
     # ---- incremental decode for streaming: audio of frames [t0, T) given all codes so far.  Bit-identical to
     # from_indices(final codes)[..., t0*frame_length : T*frame_length] because every codec layer is causal

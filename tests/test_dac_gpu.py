@@ -116,6 +116,23 @@ def test_causal_prefix_and_batch_invariance_at_10s(full):
     assert float((part[0, 0] - both[0, 0, : 100 * 2048]).abs().max()) <= 2e-5
 
 
+def test_ragged_batched_decode_equals_decoding_every_utterance_alone(full):
+    """MiDAC.from_indices_ragged (round 4; the batched decode of tools/server/model_utils.py:61-86 for utterances of
+    different lengths): eleven utterances of 1..430 frames, grouped by length, each group padded at its end and
+    decoded by one call -- every utterance's samples equal its own batch-1 decode bit for bit (causal layers,
+    batch-invariant kernels), in the caller's order; an empty utterance yields an empty waveform."""
+    cfg, state, codec = full
+    lens = [215, 1, 430, 100, 0, 333, 215, 64, 7, 128, 250]
+    codes = [D.make_codes(cfg, 1, max(t, 1), seed=60 + i)[0, :, :t].to(DEV) for i, t in enumerate(lens)]
+    got = codec.from_indices_ragged(codes)
+    assert len(got) == len(lens)
+    for i, t in enumerate(lens):
+        assert got[i].shape == (1, 1, t * codec.frame_length), (i, got[i].shape)
+        if t:
+            alone = codec.from_indices(codes[i][None].clone())
+            assert torch.equal(got[i], alone), f"utterance {i} ({t} frames) differs from its batch-1 decode"
+
+
 def test_baseline_shape_from_indices_2x215_and_inside_a_batch_of_8_vs_oracle(full):
     """The BASELINE decode shape against the oracle: two 215-frame utterances (10 s each,
     440 320 samples) decoded by the CPU oracle; the HIP codec must match them (RMS <= 1e-4) decoded as a batch of 2

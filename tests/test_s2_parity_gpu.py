@@ -246,7 +246,13 @@ def test_s2_serve_stream_two_staggered_requests_equal_the_fixtures_and_the_offli
         T = z["prompt"].shape[1]
         want = torch.from_numpy(z["tokens"])[1:, T:-1]                      # inference.py:708
         audio, codes = got[i]
-        assert torch.equal(codes, want), f"request {i}: streamed codes differ from the reference's fixture"
+        # the codec clamps the indices it is handed IN PLACE to its codebook sizes like the reference (rvq.py:354-359;
+        # this synthetic pairing has 4096-code fast codebooks in front of 1024-entry residual quantizers), and the
+        # events carry what was voiced
+        clamped = want.clone()
+        clamped[0].clamp_(max=dcfg.semantic_codebook_size - 1)
+        clamped[1:].clamp_(max=dcfg.codebook_size - 1)
+        assert torch.equal(codes, clamped), f"request {i}: streamed codes differ from the reference's fixture"
         off = codec.from_indices(want[None].clone().to(DEV))[0, 0].cpu()
         assert torch.equal(audio, off), f"request {i}: streamed audio differs from the offline decode"
     codec.stream_reset()

@@ -1,6 +1,6 @@
 // gemm_bench.hip -- the prefill GEMM variants (launch_linear_tiled: 'l' 4-wave LDS-staged, 'w' wave-specialised, 'x' the
 // 8-compute-wave 128 x 256 tile) on the S2-Pro prefill shapes, M = 8 x 200 and 8 x 2048 rows (round 3).
-// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFMI_WS_ABLATE=n] tools/gemm_bench.hip fish_speech_amd/csrc/common.cpp -o tools/bin/gemm_bench
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFMI_WS_ABLATE=n] tools/gemm_bench.hip fish_speech_amd/csrc/dualar_kernels.hip fish_speech_amd/csrc/common.cpp -o tools/bin/gemm_bench
 // Usage:  [GEMM_MS=m1,m2,...] gemm_bench [variants, default lw] [shape name] [M]
 //   FMI_WS_ABLATE (resource ablation of the 'w' kernel, results are garbage): 1 = the loader waves issue only the first
 //   two stages (no DMA in the steady state), 2 = no MFMA (operand reads only), 3 = no operand reads (MFMA on stale registers)
@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <map>
+#include <algorithm>
 #include "../fish_speech_amd/csrc/dualar_gemm.hip"
 
 using namespace fmi;
@@ -114,7 +116,7 @@ int main(int argc, char** argv) {
       printf("M=%5d %-6s N=%5d K=%5d :", M, sh.name, sh.N, sh.K);
       int vi = 0;
       for (const char* v = variants; *v; ++v, ++vi) {
-        const int variant = *v == 'l' ? 1 : *v == 'w' ? 2 : 3;
+        const int variant = *v == 'l' ? 1 : *v == 'w' ? 2 : *v == 'x' ? 3 : *v == 'y' ? 4 : *v == 'p' ? 7 : *v == 'q' ? 8 : *v == 'r' ? 9 : 10;
         a.out = out; a.wp = w[0];
         CK(hipMemset(out, 0xff, hr.size() * 2));
         if (launch_linear_tiled(a, 0, false, variant)) { printf("launch failed: %s\n", g_last_error.c_str()); return 1; }
@@ -135,6 +137,34 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / iters;
         total[vi] += us;
         printf("  %c %8.1f us %6.0f TF/s%s", *v, us, flop / us * 1e-6, bad ? " DIFF" : "");
+#if defined(FMI_Y_TIMING)
+        if (variant >= 4) {
+          long long t[8]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ytime), sizeof(t)));
+          printf(" [wg(0,0) us: prologue %.2f loop %.2f epilogue %.2f]", (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01);
+          if (getenv("GEMM_WGLOG")) {   // per-CU timeline of the LAST launch: busy ticks, gaps between consecutive work-groups
+            const int nwg = ((sh.N / 16 + 15) / 16) * ((M + 255) / 256);
+            std::vector<long long> lg((size_t)8192 * 4);
+            CK(hipMemcpyFromSymbol(lg.data(), HIP_SYMBOL(g_ylog), lg.size() * 8));
+            std::map<long long, std::vector<std::pair<long long, long long>>> cu;
+            long long tmin = 1LL << 62, tmax = 0;
+            for (int i = 0; i < nwg && i < 8192; ++i) {
+              const long long hw = lg[i * 4 + 2], xcc = lg[i * 4 + 3] & 0xf;
+              const long long key = (xcc << 16) | (hw & 0xff00);   // xcc | se, sh, cu bits
+              cu[key].push_back({lg[i * 4], lg[i * 4 + 1]});
+              if (lg[i * 4]) tmin = std::min(tmin, lg[i * 4]);
+              tmax = std::max(tmax, lg[i * 4 + 1]);
+            }
+            double busy = 0, gaps = 0; long long ngap = 0; size_t mx = 0, mn = 1 << 30;
+            for (auto& kv : cu) {
+              auto& v = kv.second; std::sort(v.begin(), v.end());
+              mx = std::max(mx, v.size()); mn = std::min(mn, v.size());
+              for (size_t j = 0; j < v.size(); ++j) { busy += v[j].second - v[j].first; if (j) { gaps += v[j].first - v[j - 1].second; ++ngap; } }
+            }
+            printf("\n      [%d wgs on %zu CUs (%zu..%zu per CU): span %.1f us, mean busy %.2f us per wg, mean gap %.2f us]",
+                   nwg, cu.size(), mn, mx, (tmax - tmin) * 0.01, busy / nwg * 0.01, ngap ? gaps / ngap * 0.01 : 0.0);
+          }
+        }
+#endif
       }
       printf("\n");
       hipFree(raw); hipFree(x); hipFree(res); hipFree(out); hipFree(ref); for (auto p : w) hipFree(p);
