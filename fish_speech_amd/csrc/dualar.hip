@@ -1380,8 +1380,8 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
   a.K = K; a.epi = epilogue;
   // 2: tiled (default variant), 5: tiled, operands straight from L2, 6: skinny on the row-balanced copy (must exist),
   // 7: tiled, LDS-staged 4-wave kernel, 8: tiled, LDS-staged wave-specialised kernel, 9: its 128 x 256-tile variant,
-  // 10 / 11: linear_tiled_256p_kernel with 256 / 128-row tiles (round 4, what the shape selects), 12: the 16-wave and
-  // 13: the plain 8-wave 256 x 256 kernels (A/B)
+  // 10 / 11 / 14 / 15: linear_tiled_256p_kernel with 256 / 128 / 64 / 192-row tiles (round 4, what the shape selects among),
+  // 12: the 16-wave and 13: the plain 8-wave 256 x 256 kernels (A/B)
   const bool skinny = force_path == 1 || force_path == 6 || (force_path == 0 && M <= 16);
   bf16_t* rowcopy = nullptr;
   if (rc == FMI_OK && force_path == 6) {
@@ -1404,7 +1404,7 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
         a.x = xn;
         a.norm_w = nullptr;
       }
-      if (rc == FMI_OK) rc = launch_linear_tiled(a, s, force_path == 5, force_path == 7 ? 1 : force_path == 8 ? 2 : force_path == 9 ? 3 : force_path == 10 ? 7 : force_path == 11 ? 10 : force_path == 12 ? 9 : force_path == 13 ? 4 : 0);
+      if (rc == FMI_OK) rc = launch_linear_tiled(a, s, force_path == 5, force_path == 7 ? 1 : force_path == 8 ? 2 : force_path == 9 ? 3 : force_path == 10 ? 7 : force_path == 11 ? 10 : force_path == 12 ? 9 : force_path == 13 ? 4 : force_path == 14 ? 11 : force_path == 15 ? 12 : 0);
     }
   }
   hipStreamSynchronize(s);

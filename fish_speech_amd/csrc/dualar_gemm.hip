@@ -665,6 +665,7 @@ __global__ __launch_bounds__(512, 2) void linear_tiled_256_kernel(LinearArgs a) 
 template <int EPI, bool W3, int MF = 8>
 __global__ __launch_bounds__(512, 2) void linear_tiled_256p_kernel(LinearArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // X stages 2 x 32 KiB | W stages (2 or 3) x 32 KiB
+  static_assert(MF == 2 || MF == 4 || MF == 6 || MF == 8, "linear_tiled_256p_kernel: 64 / 128 / 192 / 256-row tiles");
   constexpr int BM = 32 * MF, XPW = MF / 2;       // rows of the tile; activation pieces (8 rows x 128 B) per wave and step
   constexpr int XS = BM * 128, WOFF = 2 * XS, WSN = W3 ? 3 : 2;
   FMI_YSTAMP(0);
@@ -741,9 +742,18 @@ __global__ __launch_bounds__(512, 2) void linear_tiled_256p_kernel(LinearArgs a)
                    : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]),    \
                      "+v"(x[MF - 4]), "+v"(x[MF - 3]), "+v"(x[MF - 2]), "+v"(x[MF - 1])                                 \
                    :: "memory");                                                                                        \
-    else                                                                                                                \
+    else if constexpr (MF == 6)                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+                   : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]),    \
+                     "+v"(x[MF - 2]), "+v"(x[MF - 1])                                                                   \
+                   :: "memory");                                                                                        \
+    else if constexpr (MF == 4)                                                                                         \
       asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
                    : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])     \
+                   :: "memory");                                                                                        \
+    else                                                                                                                \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+                   : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(x[0]), "+v"(x[1])                             \
                    :: "memory");                                                                                        \
   } while (0)
   // dma: this block also issues the wave's NP DMA pieces -- activations of step ksx first, then weights of step ksw --
@@ -926,18 +936,29 @@ int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, i
   dim3 grid(cdiv(a.N / 16, 8), cdiv(a.M, 128)), block(256);
   // A/B switch: FMI_GEMM = d (operands straight from L2), l (LDS-staged, 4 waves), w (LDS-staged, wave-specialised)
   static const char env_mode = []() { const char* e = getenv("FMI_GEMM"); return e ? e[0] : '\0'; }();
-  char mode = force_direct ? 'd' : variant == 1 ? 'l' : variant == 2 ? 'w' : variant == 3 ? 'x' : variant == 4 ? 'y' : variant == 7 ? 'p' : variant == 8 ? 'q' : variant == 9 ? 'r' : variant == 10 ? 's' : env_mode ? env_mode : FMI_GEMM_DEFAULT;
+  char mode = force_direct ? 'd' : variant == 1 ? 'l' : variant == 2 ? 'w' : variant == 3 ? 'x' : variant == 4 ? 'y' : variant == 7 ? 'p' : variant == 8 ? 'q' : variant == 9 ? 'r' : variant == 10 ? 's' : variant == 11 ? 't' : variant == 12 ? 'u' : env_mode ? env_mode : FMI_GEMM_DEFAULT;
   if (mode == 'a') {
-    // Round 4: the 256-column tiles of linear_tiled_256p_kernel, 256 or 128 rows by which finishes first on 256 CUs --
-    // rounds of one work-group per CU, a 128-row work-group taking ~0.58 of a 256-row one (tools/gemm_bench sweep over
-    // 200 .. 16384 rows, profiles/r04_gemm_bench.txt: at 8 x 200 rows wqkv 98 -> 65 us, wo 74 -> 61, w1|w3 259 -> 205,
-    // w2 162 -> 137; at 8 x 2048 rows the layer 4.70 -> 3.28 ms).  All variants give identical bits, so the choice may
-    // depend on the row count without touching batch invariance.
-    const int ct = cdiv(a.N, 256), tp = ct * cdiv(a.M, 256), ts = ct * cdiv(a.M, 128);
-    mode = (cdiv(ts, 256) * 58 < cdiv(tp, 256) * 100) ? 's' : 'p';
+    // Round 4: the 256-column tiles of linear_tiled_256p_kernel, 256 / 192 / 128 / 64 rows by which finishes first on
+    // 256 CUs.  Cost model fitted to the tools/gemm_bench sweep over 200 .. 16384 rows (profiles/r04_gemm_bench.txt
+    // section 12): rounds of one work-group per CU (two for the 64-row form), a work-group of 256 / 192 / 128 / 64
+    // rows costing 1.0 / 0.76 / 0.60 / 0.69 (per round of 512) when the chip is full and 1.0 / 0.83 / 0.69 / 0.59
+    // in a single, under-filled round (a work-group streams its 256 weight columns whatever its row count).  At 8 x 200
+    // rows: wqkv 98 -> 53 us, wo 74 -> 55, w1|w3 259 -> 185, w2 162 -> 132; at 8 x 2048 rows the layer 4.70 -> 3.28 ms.
+    // All variants give identical bits, so the choice may depend on the row count without touching batch invariance.
+    const int ct = cdiv(a.N, 256);
+    auto cost = [&](int mf) {
+      static const int w_full[5] = {0, 69, 60, 76, 100}, w_lone[5] = {0, 59, 69, 83, 100};
+      const int wgs = ct * cdiv(a.M, 32 * mf), rounds = cdiv(wgs, mf == 2 ? 512 : 256);
+      if (rounds == 1) return (mf == 2 && wgs > 256) ? 69 : w_lone[mf / 2];
+      return rounds * w_full[mf / 2];
+    };
+    int best = 8;
+    for (int mf = 6; mf >= 2; mf -= 2)
+      if (cost(mf) < cost(best)) best = mf;
+    mode = best == 8 ? 'p' : best == 6 ? 'u' : best == 4 ? 's' : 't';
   }
-  if ((mode == 'w' || mode == 'x' || mode == 'y' || mode == 'p' || mode == 'q' || mode == 'r' || mode == 's') && ((a.K >> 5) & 1)) mode = 'l';   // these loops take k-tiles in pairs
-  if ((mode == 'y' || mode == 'p' || mode == 'q' || mode == 'r' || mode == 's') && (a.ldo % 8 != 0 || (a.epi == EPI_RESIDUAL && a.ldr % 8 != 0) || a.N % 8 != 0))
+  if ((mode == 'w' || mode == 'x' || mode == 'y' || mode == 'p' || mode == 'q' || mode == 'r' || mode == 's' || mode == 't' || mode == 'u') && ((a.K >> 5) & 1)) mode = 'l';   // these loops take k-tiles in pairs
+  if ((mode == 'y' || mode == 'p' || mode == 'q' || mode == 'r' || mode == 's' || mode == 't' || mode == 'u') && (a.ldo % 8 != 0 || (a.epi == EPI_RESIDUAL && a.ldr % 8 != 0) || a.N % 8 != 0))
     mode = 'w';         // the 256 x 256 kernels write 16-byte row chunks
   if (mode == 'r') {   // 256 x 256 tile on sixteen waves
     constexpr int smem_r = 2 * 65536;
@@ -953,7 +974,7 @@ int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, i
     return FMI_OK;
   }
   if (mode == 'q') mode = 'p';   // (W3 = true: weights two steps ahead through a third stage -- measured no faster, profiles/r04_gemm_bench.txt; not instantiated)
-  if (mode == 'p' || mode == 's') {   // 256 (s: 128) x 256 tile, products deferred across the barrier
+  if (mode == 'p' || mode == 's' || mode == 't' || mode == 'u') {   // 256 (u: 192, s: 128, t: 64) x 256 tile, products deferred across the barrier
 #define FMI_LAUNCH_P(W3_, MF_, SMEM_)                                                                                              \
     do {                                                                                                                            \
       static const hipError_t y0 = hipFuncSetAttribute((const void*)linear_tiled_256p_kernel<EPI_STORE, W3_, MF_>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_);    \
@@ -965,7 +986,10 @@ int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, i
       else if (a.epi == EPI_RESIDUAL) hipLaunchKernelGGL((linear_tiled_256p_kernel<EPI_RESIDUAL, W3_, MF_>), grid_y, dim3(512), SMEM_, s, a); \
       else hipLaunchKernelGGL((linear_tiled_256p_kernel<EPI_SILU, W3_, MF_>), grid_y, dim3(512), SMEM_, s, a);                      \
     } while (0)
-    if (mode == 's') FMI_LAUNCH_P(false, 4, 131072);   // (96 KiB of stages; the epilogue parks 8 x 8 KiB)
+    // LDS = two stages of (32 MF rows x 128 B activations + 32 KiB weights); the epilogue's 8 x MF x 2 KiB fit inside
+    if (mode == 's') FMI_LAUNCH_P(false, 4, 98304);
+    else if (mode == 't') FMI_LAUNCH_P(false, 2, 81920);    // (80 KiB and 98 registers: two work-groups per CU)
+    else if (mode == 'u') FMI_LAUNCH_P(false, 6, 114688);
     else FMI_LAUNCH_P(false, 8, 131072);
 #undef FMI_LAUNCH_P
     FMI_CHECK_HIP(hipGetLastError());

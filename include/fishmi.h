@@ -200,8 +200,8 @@ int fmi_dualar_last_decode_stats(fmi_dualar* h, float* ms, int* launches_per_fra
  * 2 = SwiGLU pairing silu(w1 x)*w3 x with W = [w1;w3] stacked (llama.py:979-987).
  * force_path: 0 auto, 1 skinny (M<=16), 2 tiled GEMM (the variant the shape selects), 5 tiled GEMM with operands
  * straight from L2, 7 / 8 / 9 the LDS-staged 4-wave / wave-specialised 128x128 / wave-specialised 128x256 kernels,
- * 10 / 11 the 256 / 128-row x 256-column tiles of round 4 (what 2 selects), 12 / 13 their 16-wave / plain 8-wave forms
- * (2, 5, 7 - 13 agree bit for bit), 6 skinny on the row-balanced weight copy. */
+ * 10 / 11 / 14 / 15 the 256 / 128 / 64 / 192-row x 256-column tiles of round 4 (what 2 selects among), 12 / 13 their
+ * 16-wave / plain 8-wave forms (2, 5, 7 - 15 agree bit for bit), 6 skinny on the row-balanced weight copy. */
 int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_dev,
                        const void* residual_dev, void* out_dev, int M, int N, int K, float eps,
                        int epilogue, int force_path, void* stream);

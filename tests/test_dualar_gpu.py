@@ -151,9 +151,9 @@ def test_lds_staged_prefill_gemm_equals_the_direct_variant(lib, M, N, K, epi):
     # its 128 x 256-tile form (8 compute + 4 loader waves, three stages), taken by shape once it fills the chip
     wide = _linear(lib, x, w, None, res, M, N, K, epi, 9)
     assert torch.equal(wide, direct), float((wide.float() - direct.float()).abs().max())
-    # round 4: 256-column tiles, one 8-wave work-group per CU, products deferred across the barrier (256 / 128 rows),
+    # round 4: 256-column tiles, one 8-wave work-group per CU, products deferred across the barrier (256 / 128 / 64 / 192 rows),
     # and the 16-wave / plain forms kept for A/B; all stage whole 128-byte activation lines and store through LDS
-    for path in (10, 11, 12, 13):
+    for path in (10, 11, 12, 13, 14, 15):
         y = _linear(lib, x, w, None, res, M, N, K, epi, path)
         assert torch.equal(y, direct), (path, float((y.float() - direct.float()).abs().max()))
     assert torch.equal(_linear(lib, x, w, None, res, M, N, K, epi, 2), direct)   # whichever the shape selects

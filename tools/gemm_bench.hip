@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
       printf("M=%5d %-6s N=%5d K=%5d :", M, sh.name, sh.N, sh.K);
       int vi = 0;
       for (const char* v = variants; *v; ++v, ++vi) {
-        const int variant = *v == 'l' ? 1 : *v == 'w' ? 2 : *v == 'x' ? 3 : *v == 'y' ? 4 : *v == 'p' ? 7 : *v == 'q' ? 8 : *v == 'r' ? 9 : 10;
+        const int variant = *v == 'l' ? 1 : *v == 'w' ? 2 : *v == 'x' ? 3 : *v == 'y' ? 4 : *v == 'p' ? 7 : *v == 'q' ? 8 : *v == 'r' ? 9 : *v == 's' ? 10 : *v == 't' ? 11 : 12;
         a.out = out; a.wp = w[0];
         CK(hipMemset(out, 0xff, hr.size() * 2));
         if (launch_linear_tiled(a, 0, false, variant)) { printf("launch failed: %s\n", g_last_error.c_str()); return 1; }
