@@ -38,8 +38,9 @@ struct Workspace {
   int rows = 0;
   bf16_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *ao = nullptr, *act = nullptr;
   int32_t *row_slot = nullptr, *row_pos = nullptr, *last_rows = nullptr;
-  int4* qtiles = nullptr;   // prefill attention: 16-row query tiles {row0, rows, slot, first position}
+  int4* qtiles = nullptr;   // prefill attention: query tiles {row0, rows, slot, first position}
   int n_qtiles = 0;
+  int qtile_rows = 16;      // rows per tile: 16, 32 or 48 (chosen per prefill call from the row count)
 };
 
 }  // namespace
@@ -352,7 +353,7 @@ int block_slow(fmi_dualar* h, const LayerW& w, int layer, bf16_t* x, int rows, c
     }
   } else {
     FMI_CHECK(launch_attn_prep(a, s));
-    a.qtiles = ws.qtiles; a.n_qtiles = ws.n_qtiles;
+    a.qtiles = ws.qtiles; a.n_qtiles = ws.n_qtiles; a.qtile_rows = ws.qtile_rows;
     if (h->attn_impl == 1 && ws.n_qtiles > 0) FMI_CHECK(launch_attn_prefill_mfma(a, s));
     else FMI_CHECK(launch_attn(a, s));
     h->launches += 2;
@@ -991,6 +992,11 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
   FMI_CHECK(ensure_rows(h, std::max(rows, std::max(h->max_batch, std::min(16, 2 * h->max_batch)))));
   std::vector<int32_t> row_slot(rows), row_pos(rows), last(n), slots(n);
   std::vector<int4> tiles;
+  // rows per query tile of the prefill attention (1 / 2 / 3 column groups per work-group share the staged K/V blocks):
+  // long prefills take the wide tiles, short ones keep the work-group count up.  Output bits do not depend on it.
+  static const int env_mq = []() { const char* e = getenv("FMI_ATTN_MQ"); return e ? atoi(e) : 0; }();
+  const int qrows = (env_mq >= 1 && env_mq <= 3) ? 16 * env_mq : rows >= 4096 ? 48 : rows >= 2048 ? 32 : 16;
+  h->ws.qtile_rows = qrows;
   int r = 0;
   for (int i = 0; i < n; ++i) {
     const int p0 = pos0 ? pos0[i] : 0;
@@ -1003,8 +1009,8 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
     // stops appending once SlotState.done is set)
     FMI_CHECK(reserve_pages(h, slot_ids[i], std::min(std::max(limit, full) + 1, h->max_seq)));
     FMI_CHECK(set_slot(h, slot_ids[i], full, frame_index, limit, samp[i], frame_index == 0));
-    for (int t0 = 0; t0 < lens[i]; t0 += 16)
-      tiles.push_back(make_int4(r + t0, std::min(16, lens[i] - t0), slot_ids[i], p0 + t0));
+    for (int t0 = 0; t0 < lens[i]; t0 += qrows)
+      tiles.push_back(make_int4(r + t0, std::min(qrows, lens[i] - t0), slot_ids[i], p0 + t0));
     for (int t = 0; t < lens[i]; ++t, ++r) {
       row_slot[r] = slot_ids[i];
       row_pos[r] = p0 + t;

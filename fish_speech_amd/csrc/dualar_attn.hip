@@ -196,8 +196,21 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 //           halves (two MFMAs: the weights keep ~16 significant bits, the reference multiplies fp32 weights).
 // Causal tiles are skipped (key blocks beyond the tile's last position are never visited), the diagonal block is
 // masked by select.  Tile descriptors (row0, rows, slot, first position) come from the host, heaviest first.
-template <int D, int G>
-__global__ __launch_bounds__(64 * G) void attn_prefill_mfma_kernel(AttnArgs a) {
+// MQ (round 4) = 16-row query tiles per work-group (tile descriptors then cover up to 16 MQ rows): the staged K/V block and
+// its fragment reads are shared by MQ column groups -- with one group a 32-key block cost two barriers and 16 KiB of
+// staging for 24 products per wave (1.18 ms per layer at 8 x 2048 tokens: 0.09 of the matrix peak).  A query row's
+// arithmetic does not depend on the group it sits in (key blocks past a group's own last position are skipped, exactly
+// as its own 16-row work-group would), so the output bits do not depend on MQ.  The bf16 hi + lo split of the
+// probabilities and the output rounding use v_cvt_pk_bf16_f32 (round-to-nearest-even like f2bf, 2 values per
+// instruction instead of 7 integer operations per value).
+__device__ inline uint32_t attn_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int D, int G, int MQ>
+__global__ __launch_bounds__(64 * G, MQ > 1 ? 2 : 1) void attn_prefill_mfma_kernel(AttnArgs a) {
   constexpr int KB = 32, NT = 64 * G, DC = D / 8;
   constexpr int KROW = D + 8;                 // bf16 elements per s_k row (+16 bytes)
   constexpr int VROWB = KB * 2 + 8;           // bytes per s_vt row (32 keys + 8 bytes pad)
@@ -205,10 +218,11 @@ __global__ __launch_bounds__(64 * G) void attn_prefill_mfma_kernel(AttnArgs a) {
   constexpr int KCH = KB * DC / NT > 0 ? KB * DC / NT : 1;        // 16-byte K chunks per thread
   constexpr int VCH = (KB / 2) * DC / NT > 0 ? (KB / 2) * DC / NT : 1;  // key-pair chunks per thread
   static_assert((KB * DC) % NT == 0 || KB * DC < NT, "K staging");
+  constexpr bool KFULL = (KB * DC) % NT == 0, VFULL = ((KB / 2) * DC) % NT == 0;   // every thread has work in every staging pass
   __shared__ __attribute__((aligned(16))) bf16_t s_k[KB * KROW];
   __shared__ __attribute__((aligned(16))) unsigned char s_vt[VROWS * VROWB];
 
-  const int4 td = a.qtiles[blockIdx.x];  // x row0, y rows (1..16), z slot, w first position
+  const int4 td = a.qtiles[blockIdx.x];  // x row0, y rows (1..16 MQ), z slot, w first position
   const int kvh = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
@@ -217,46 +231,53 @@ __global__ __launch_bounds__(64 * G) void attn_prefill_mfma_kernel(AttnArgs a) {
   const int32_t* bt = a.block_table + (int64_t)td.z * a.max_pages;
   const int last_pos = td.w + td.y - 1;
   const int n_blocks = last_pos / KB + 1;
-  const int qpos = td.w + c;
 
-  // Q^T fragments (B operand: column = query c, k rows = d chunk g of k-step kk)
-  bf16x8 qf[D / 32];
-  {
-    const int qrow = td.x + (c < td.y ? c : td.y - 1);
+  // Q^T fragments (B operand: column = query 16 q + c, k rows = d chunk g of k-step kk)
+  bf16x8 qf[MQ][D / 32];
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) {
+    const int qrow = td.x + min(16 * q + c, td.y - 1);
     const bf16_t* qp = a.q + ((int64_t)qrow * H + head) * D + g * 8;
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32);
+    for (int kk = 0; kk < D / 32; ++kk) qf[q][kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32);
   }
 
-  f32x4 o[D / 16];
+  f32x4 o[MQ][D / 16];
+  float m[MQ], l[MQ];
 #pragma unroll
-  for (int dt = 0; dt < D / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m = -1e30f, l = 0.f;
+  for (int q = 0; q < MQ; ++q) {
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) o[q][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m[q] = -1e30f;
+    l[q] = 0.f;
+  }
   const float scale = 1.0f / sqrtf((float)D);
 
   // ---- staging helpers: K chunk i -> (key i / DC, dchunk i % DC); V chunk i -> (key pair i / DC, dchunk i % DC)
-  uint4 kreg[KCH], vreg[VCH][2];
+  // (vector types, not HIP's uint4 struct: copied as a struct the K registers were kept in SCRATCH -- stored right behind
+  // their global load and re-loaded for the LDS write, which also made the 'prefetch' wait for the load at once)
+  u32x4 kreg[KCH], vreg[VCH][2];
   auto fetch = [&](int kb) {
     const int page = bt[(kb * KB) / KV_PAGE];
     const int64_t pbase = ((int64_t)page * KVH + kvh) * KV_PAGE + (kb * KB) % KV_PAGE;
 #pragma unroll
     for (int it = 0; it < KCH; ++it) {
       const int i = tid + it * NT;
-      if (i < KB * DC) {
+      if (KFULL || i < KB * DC) {
         const int key = i / DC, dc = i % DC;
-        kreg[it] = *reinterpret_cast<const uint4*>(a.kpool + (pbase + key) * D + dc * 8);
+        kreg[it] = *reinterpret_cast<const u32x4*>(a.kpool + (pbase + key) * D + dc * 8);
       }
     }
 #pragma unroll
     for (int it = 0; it < VCH; ++it) {
       const int i = tid + it * NT;
-      if (i < (KB / 2) * DC) {
+      if (VFULL || i < (KB / 2) * DC) {
         const int kp = i / DC, dc = i % DC;
         const bool v0 = kb * KB + 2 * kp <= last_pos, v1 = kb * KB + 2 * kp + 1 <= last_pos;
         // rows beyond the tile's last position have not been written (stale pool contents): they must read as 0,
         // a masked probability of 0 times a stale NaN/Inf would poison the accumulator
-        vreg[it][0] = v0 ? *reinterpret_cast<const uint4*>(a.vpool + (pbase + 2 * kp) * D + dc * 8) : make_uint4(0, 0, 0, 0);
-        vreg[it][1] = v1 ? *reinterpret_cast<const uint4*>(a.vpool + (pbase + 2 * kp + 1) * D + dc * 8) : make_uint4(0, 0, 0, 0);
+        vreg[it][0] = v0 ? *reinterpret_cast<const u32x4*>(a.vpool + (pbase + 2 * kp) * D + dc * 8) : (u32x4){0, 0, 0, 0};
+        vreg[it][1] = v1 ? *reinterpret_cast<const u32x4*>(a.vpool + (pbase + 2 * kp + 1) * D + dc * 8) : (u32x4){0, 0, 0, 0};
       }
     }
   };
@@ -264,18 +285,18 @@ __global__ __launch_bounds__(64 * G) void attn_prefill_mfma_kernel(AttnArgs a) {
 #pragma unroll
     for (int it = 0; it < KCH; ++it) {
       const int i = tid + it * NT;
-      if (i < KB * DC) *reinterpret_cast<uint4*>(&s_k[(i / DC) * KROW + (i % DC) * 8]) = kreg[it];
+      if (KFULL || i < KB * DC) *reinterpret_cast<u32x4*>(&s_k[(i / DC) * KROW + (i % DC) * 8]) = kreg[it];
     }
 #pragma unroll
     for (int it = 0; it < VCH; ++it) {
       const int i = tid + it * NT;
-      if (i < (KB / 2) * DC) {
+      if (VFULL || i < (KB / 2) * DC) {
         const int kp = i / DC, dc = i % DC;
-        const bf16_t* e0 = reinterpret_cast<const bf16_t*>(&vreg[it][0]);
-        const bf16_t* e1 = reinterpret_cast<const bf16_t*>(&vreg[it][1]);
+        // element j of the two keys side by side: one v_perm_b32 per dword (no element-wise register addressing)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          *reinterpret_cast<uint32_t*>(&s_vt[(j * (DC + 1) + dc) * VROWB + kp * 4]) = (uint32_t)e0[j] | ((uint32_t)e1[j] << 16);
+          *reinterpret_cast<uint32_t*>(&s_vt[(j * (DC + 1) + dc) * VROWB + kp * 4]) =
+              __builtin_amdgcn_perm(vreg[it][1][j >> 1], vreg[it][0][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
       }
     }
   };
@@ -287,49 +308,62 @@ __global__ __launch_bounds__(64 * G) void attn_prefill_mfma_kernel(AttnArgs a) {
     __syncthreads();
     if (kb + 1 < n_blocks) fetch(kb + 1);
 
-    // ---- scores: two 16-key tiles, lane (c, g) ends up with keys kt*16 + g*4 + j of query column c
-    f32x4 sacc[2];
+    // ---- scores: two 16-key tiles per column group, lane (c, g) ends up with keys kt*16 + g*4 + j of query column c.
+    // (A group whose rows all lie before this key block is done: its own 16-row work-group would have stopped.)
+    bool act[MQ];
+    f32x4 sacc[MQ][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      sacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < D / 32; ++kk) {
-        const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(&s_k[(kt * 16 + c) * KROW + kk * 32 + g * 8]);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[kk], sacc[kt], 0, 0, 0);
-      }
+    for (int q = 0; q < MQ; ++q) {
+      act[q] = 16 * q < td.y && kb * KB <= td.w + min(16 * q + 15, td.y - 1);
+      sacc[q][0] = sacc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    float sc[8];
-    float mx = -1e30f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = kb * KB + kt * 16 + g * 4 + j;
-        const float v = key <= qpos ? sacc[kt][j] * scale : -1e30f;
-        sc[kt * 4 + j] = v;
-        mx = fmaxf(mx, v);
+      for (int kk = 0; kk < D / 32; ++kk) {
+        const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(&s_k[(kt * 16 + c) * KROW + kk * 32 + g * 8]);
+#pragma unroll
+        for (int q = 0; q < MQ; ++q)
+          if (act[q]) sacc[q][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[q][kk], sacc[q][kt], 0, 0, 0);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float corr = __expf(m - mn);
-    float ps = 0.f, pr[8];
+    u32x4 ph[MQ], pl[MQ];      // probabilities as the B operand (k slots g*8 + jj = keys {g*4 + jj | jj < 4} and {16 + g*4 + jj - 4}), hi + lo
+    float corr[MQ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      pr[j] = sc[j] > -1e29f ? __expf(sc[j] - mn) : 0.f;
-      ps += pr[j];
-    }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
-    l = l * corr + ps;
-    m = mn;
-    // probabilities as the B operand (k slots g*8 + jj = keys {g*4 + jj | jj < 4} and {16 + g*4 + jj - 4}), hi + lo
-    bf16x8 ph, pl;
+    for (int q = 0; q < MQ; ++q) {
+      corr[q] = 1.f;
+      if (!act[q]) continue;
+      const int qpos = td.w + 16 * q + c;
+      float sc[8];
+      float mx = -1e30f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bf16_t hi = f2bf(pr[j]);
-      ph[j] = (short)hi;
-      pl[j] = (short)f2bf(pr[j] - bf2f(hi));
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = kb * KB + kt * 16 + g * 4 + j;
+          const float v = key <= qpos ? sacc[q][kt][j] * scale : -1e30f;
+          sc[kt * 4 + j] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[q], mx);
+      corr[q] = __expf(m[q] - mn);
+      float ps = 0.f, pr[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pr[j] = sc[j] > -1e29f ? __expf(sc[j] - mn) : 0.f;
+        ps += pr[j];
+      }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      l[q] = l[q] * corr[q] + ps;
+      m[q] = mn;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t hi = attn_pk_bf16(pr[2 * j], pr[2 * j + 1]);
+        ph[q][j] = hi;
+        pl[q][j] = attn_pk_bf16(pr[2 * j] - __uint_as_float(hi << 16), pr[2 * j + 1] - __uint_as_float(hi & 0xffff0000u));
+      }
     }
 #pragma unroll
     for (int dt = 0; dt < D / 16; ++dt) {
@@ -340,20 +374,25 @@ __global__ __launch_bounds__(64 * G) void attn_prefill_mfma_kernel(AttnArgs a) {
       u32x4 av = {lo.x, lo.y, hi.x, hi.y};
       const bf16x8 vfrag = *reinterpret_cast<bf16x8*>(&av);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[dt][j] *= corr;
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, ph, o[dt], 0, 0, 0);
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pl, o[dt], 0, 0, 0);
+      for (int q = 0; q < MQ; ++q) {
+        if (!act[q]) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[q][dt][j] *= corr[q];
+        o[q][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, *reinterpret_cast<bf16x8*>(&ph[q]), o[q][dt], 0, 0, 0);
+        o[q][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, *reinterpret_cast<bf16x8*>(&pl[q]), o[q][dt], 0, 0, 0);
+      }
     }
   }
 
-  if (c < td.y) {   // lane holds query column c, output dims dt*16 + g*4 + j
-    const float inv = 1.0f / l;
-    bf16_t* op = a.out + ((int64_t)(td.x + c) * H + head) * D + g * 4;
 #pragma unroll
-    for (int dt = 0; dt < D / 16; ++dt) {
-      const uint32_t w0 = (uint32_t)f2bf(o[dt][0] * inv) | ((uint32_t)f2bf(o[dt][1] * inv) << 16);
-      const uint32_t w1 = (uint32_t)f2bf(o[dt][2] * inv) | ((uint32_t)f2bf(o[dt][3] * inv) << 16);
-      *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(w0, w1);
+  for (int q = 0; q < MQ; ++q) {
+    if (16 * q + c < td.y) {   // lane holds query column 16 q + c, output dims dt*16 + g*4 + j
+      const float inv = 1.0f / l[q];
+      bf16_t* op = a.out + ((int64_t)(td.x + 16 * q + c) * H + head) * D + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt)
+        *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(attn_pk_bf16(o[q][dt][0] * inv, o[q][dt][1] * inv),
+                                                            attn_pk_bf16(o[q][dt][2] * inv, o[q][dt][3] * inv));
     }
   }
 }
@@ -362,12 +401,20 @@ template <int D>
 static int launch_attn_prefill_d(const AttnArgs& a, hipStream_t s) {
   const int G = a.H / a.KVH;
   dim3 grid(a.n_qtiles, a.KVH);
+  FMI_REQUIRE(a.qtile_rows == 16 || a.qtile_rows == 32 || a.qtile_rows == 48, "attn: query tiles of 16 / 32 / 48 rows");
+#define FMI_PREFILL(G_)                                                                                                     \
+  do {                                                                                                                      \
+    if (a.qtile_rows == 16) hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, G_, 1>), grid, dim3(64 * G_), 0, s, a);         \
+    else if (a.qtile_rows == 32) hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, G_, 2>), grid, dim3(64 * G_), 0, s, a);    \
+    else hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, G_, 3>), grid, dim3(64 * G_), 0, s, a);                            \
+  } while (0)
   switch (G) {
-    case 1: hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, 1>), grid, dim3(64), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, 2>), grid, dim3(128), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, 4>), grid, dim3(256), 0, s, a); break;
+    case 1: FMI_PREFILL(1); break;
+    case 2: FMI_PREFILL(2); break;
+    case 4: FMI_PREFILL(4); break;
     default: return set_error(FMI_EINVAL, "attn: GQA ratio %d unsupported", G);
   }
+#undef FMI_PREFILL
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }

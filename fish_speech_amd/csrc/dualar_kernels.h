@@ -116,8 +116,9 @@ struct AttnArgs {
   const int32_t* block_table;
   const int32_t* slot_pos;
   const int32_t* slot_done;   // decode only: a finished slot (SlotState.done != 0) no longer appends K/V
-  const int4* qtiles;         // prefill (MFMA kernel): per 16-row query tile {row0, rows, slot, first position}
+  const int4* qtiles;         // prefill (MFMA kernel): per query tile {row0, rows (<= qtile_rows), slot, first position}
   int n_qtiles;
+  int qtile_rows;             // 16, 32 or 48: rows a work-group of the prefill kernel owns (1, 2 or 3 column groups)
   int max_pages;
   int rows, H, KVH, D;
   float eps;
