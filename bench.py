@@ -669,8 +669,9 @@ def main():
                      "frac": round(achieved / 8000.0, 4),
                      "traffic": pmc_traffic(BATCH, N_FRAMES, args.int8)[0],
                      "traffic_source": pmc_traffic(BATCH, N_FRAMES, args.int8)[1],
-                     "kernel": "decode frame: 302 linear_skinny_kernel launches (weight streaming) + 36 attention, 40 fast-attention, "
-                               "10 sampler launches, replayed as one hipGraph",
+                     "kernel": f"decode frame: {launches} launches replayed as one hipGraph -- linear_skinny_kernel (weight "
+                               "streaming: 36 slow layers x 4 + the fast transformer's 9 passes x 4 layers x 4 + heads), 36 "
+                               "attention, 36 fast-attention, 10 sampler launches",
                      "bytes_per_launch": bytes_frame, "avg_launch_ms": round(avg_frame_s * 1e3, 4)},
     }
     if prefill_ms is not None:
