@@ -446,6 +446,13 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
   auto xptr = [&](int s, int p) -> const uint4* { return reinterpret_cast<const uint4*>(xbase + (int64_t)p * 128 + xoff[s]); };
   const char* __restrict__ nbase = reinterpret_cast<const char*>(a.norm_w);
 
+  // XH > 0: the norm weight vector (K / 8 = XH * WAVES * 8 <= WAVES * 64 chunks: one per thread) is requested FIRST, so
+  // that its wait -- loads return in order -- covers nothing issued after it.  Loaded inside the statistics block it sat
+  // behind the first weight tiles: an s_waitcnt vmcnt(0) there made every norm-fused launch wait for its first HBM
+  // round trip BEFORE the row statistics instead of beside them.
+  uint4 nw_stage = make_uint4(0, 0, 0, 0);
+  const bool nw_has = XH > 0 && NORM && tid < (a.K >> 3);
+  if (nw_has && a.late_epi != 2) nw_stage = reinterpret_cast<const uint4*>(a.norm_w)[tid];   // (FMI_GEMV_LATE_EPI=2: A/B)
   uint4 xh[XS][XHN];   // XH > 0: the wave's activation fragments, raw, then normalised in place
   if (XH > 0) {
 #pragma unroll
@@ -473,6 +480,9 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
       if (u < XHN) load_pair(u, pbeg + u);
+    // (pinned here: without a fence the scheduler sinks these requests below the row statistics -- they have no user
+    // before the products -- and the first HBM round trip of the launch starts a microsecond late)
+    __builtin_amdgcn_sched_barrier(0);
   } else if (nfull > 0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) load_pair(u, pbeg + u);
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     if (t < NRES) e_res[t] = 0;
     if (t < NSC) e_scale[t] = 0;
     if (t < NBIAS) e_bias[t] = 0;
-    if (e_on && !a.late_epi) {
+    if (e_on && a.late_epi != 1) {
       if (EPI == EPI_RESIDUAL) e_res[t < NRES ? t : 0] = a.res[(int64_t)e_bb * a.ldr + (tile0 + t) * ROWS + e_r];
       if (Q8 && a.scale) e_scale[t < NSC ? t : 0] = a.scale[(tile0 + t) * 16 + e_r];
       if (EPI == EPI_STORE && a.bias) e_bias[t < NBIAS ? t : 0] = a.bias[(tile0 + t) * ROWS + e_r];
@@ -520,9 +530,9 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
 #pragma unroll
   for (int s = 0; s < XS; ++s) rstd[s] = 0.f;
   if (NORM && XH > 0) {
-    // the norm weights travel through LDS (one 16-byte load per thread, read back as broadcasts after the statistics
-    // barrier): held in registers next to the fragments they cost the w1|w3 launch its third work-group per CU
-    for (int i = tid; i < (a.K >> 3); i += WAVES * 64) s_nw[i] = reinterpret_cast<const uint4*>(a.norm_w)[i];
+    // the norm weights travel through LDS (one 16-byte load per thread -- requested at the top of the kernel --, read
+    // back as broadcasts after the statistics barrier): held in registers next to the fragments they cost the w1|w3
+    // launch its third work-group per CU
     // sum of squares: lane (chunk c = lane >> 3, row) sequentially over its pairs and elements, then the eight chunk
     // lanes of the row by an xor tree (c bit 0, 1, 2), then the waves in order
 #pragma unroll
@@ -542,6 +552,8 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
       ss += __shfl_xor(ss, 32, 64);
       if (lane < 8) s_part[wave][s * 8 + lane] = ss;
     }
+    if (nw_has && a.late_epi == 2) nw_stage = reinterpret_cast<const uint4*>(a.norm_w)[tid];   // where round 4 began: behind the weight requests
+    if (nw_has) s_nw[tid] = nw_stage;
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < XS; ++s) {
@@ -640,14 +652,29 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
       if (c + 1 < nfull) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) load_pair(u, p + u);
+      } else {   // the wave's leftover pairs (fewer than UNR) are requested like one more chunk
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (p + u < pend) load_pair(u, p + u);
       }
     }
-    for (; p < pend; ++p) {  // leftover pairs of this wave, one at a time
-      bf16x8 xs[XS];
+    if (p < pend) {  // leftover pairs of this wave: ONE round trip (rounds 1-3 took them one at a time, a trip each)
+      if (nfull == 0) {
 #pragma unroll
-      for (int s = 0; s < XS; ++s) xs[s] = frag(s, p);
-      load_pair(0, p);
-      mma_pair(0, xs);
+        for (int u = 0; u < UNR; ++u)
+          if (p + u < pend) load_pair(u, p + u);
+      }
+      bf16x8 xs[UNR][XS];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (p + u < pend) {
+#pragma unroll
+          for (int s = 0; s < XS; ++s) xs[u][s] = frag(s, p + u);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (p + u < pend) mma_pair(u, xs[u]);
     }
   }
   // fold: tile 1's sums sit in columns 8-15 of the same rows; row set 1 (rows 8-15) moves to columns 8-15
@@ -692,10 +719,10 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
       bf16_t sc = 0;
-      if (a.late_epi || !Q8) {
-        if (EPI == EPI_RESIDUAL && a.late_epi) e_res[t < NRES ? t : 0] = a.res[(int64_t)bb * a.ldr + (tile0 + t) * ROWS + r];
+      if (a.late_epi == 1 || !Q8) {
+        if (EPI == EPI_RESIDUAL && a.late_epi == 1) e_res[t < NRES ? t : 0] = a.res[(int64_t)bb * a.ldr + (tile0 + t) * ROWS + r];
         if (a.scale) sc = a.scale[(tile0 + t) * 16 + r];
-        if (EPI == EPI_STORE && a.bias && a.late_epi) e_bias[t < NBIAS ? t : 0] = a.bias[(tile0 + t) * ROWS + r];
+        if (EPI == EPI_STORE && a.bias && a.late_epi == 1) e_bias[t < NBIAS ? t : 0] = a.bias[(tile0 + t) * ROWS + r];
       } else {
         sc = e_scale[t < NSC ? t : 0];
       }
@@ -730,8 +757,8 @@ static bool skinny_hold_enabled() {
   static const bool off = []() { const char* e = getenv("FMI_GEMV_NOHOLD"); return e && atoi(e) != 0; }();
   return !off;
 }
-static bool skinny_late_epi() {   // FMI_GEMV_LATE_EPI=1: residual / scale / bias loaded in the epilogue as in rounds 1-3
-  static const bool on = []() { const char* e = getenv("FMI_GEMV_LATE_EPI"); return e && atoi(e) != 0; }();
+static int skinny_late_epi() {   // FMI_GEMV_LATE_EPI=1: residual / scale / bias loaded in the epilogue as in rounds 1-3; 2: only the norm weights late
+  static const int on = []() { const char* e = getenv("FMI_GEMV_LATE_EPI"); return e ? atoi(e) : 0; }();
   return on;
 }
 // Rows 9-16 (XR = 16): the held fragments of TWO row sets (40 registers) push the SwiGLU variant to 128 registers + spills
@@ -750,7 +777,7 @@ static bool skinny_can_hold(const LinearArgs& a, int waves) {
 template <int WAVES, int UNR, int TILES>
 static int launch_skinny_t(const LinearArgs& a0, hipStream_t s) {
   LinearArgs a = a0;
-  a.late_epi = skinny_late_epi() ? 1 : 0;
+  a.late_epi = skinny_late_epi();
   const bool norm = a.norm_w != nullptr;
   const bool wide = a.M > 8;
   const bool hold = skinny_can_hold(a, WAVES);
@@ -795,7 +822,7 @@ template <int WAVES, int UNR, int TILES, int ROWS, int EPI_, bool NORM_>
 static int launch_skinny_rows(const LinearArgs& a, const RowPlan& p, hipStream_t s) {
   LinearArgs b = a;
   b.wp = a.wr;
-  b.late_epi = skinny_late_epi() ? 1 : 0;
+  b.late_epi = skinny_late_epi();
   constexpr int XH_ = NORM_ ? SKINNY_XH : 0;
   const bool hold = NORM_ && skinny_can_hold(a, WAVES);
   const dim3 grid(p.wgs), block(WAVES * 64);
@@ -835,6 +862,8 @@ int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
   const int ntile = a.N / 16;
   if (a.wr && !a.wq && !a.scale && !a.bias && skinny_rows_supported(a.N, a.K, a.epi, a.norm_w != nullptr)) {
     const RowPlan p = skinny_row_plan(a.N, a.K, a.epi);
+    // (3 / 4 / 8 pairs in flight per wave instead of 2, measured in round 4: wo 6.56 / 6.46 / 7.02 against 6.57 us, w2
+    // 11.44 / 11.82 / 12.61 against 11.69 -- the CU's ~256 outstanding cache lines are what is full, not the registers)
     if (a.epi == EPI_RESIDUAL) return launch_skinny_rows<8, 2, 1, 10, EPI_RESIDUAL, false>(a, p, s);
     return launch_skinny_rows<8, 1, 2, 12, EPI_STORE, true>(a, p, s);
   }
