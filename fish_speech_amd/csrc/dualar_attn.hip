@@ -469,14 +469,35 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
       vv[u] = *reinterpret_cast<const uint4*>(a.vpool + base);
     }
   };
-  if (wave < n_groups) load_trip(wave);
+  // The operands of phase 1 (this wave's head of the q|k|v row, its norm weights, the RoPE pair: L2 hits) are requested
+  // BEFORE the cached K/V rows (HBM) -- loads return in order, so requested after them, as rounds 1-3 did, the
+  // norm / RoPE phase could not start before the first K/V trip had landed, and its three small loads were three
+  // dependent round trips of their own.  Now the K/V trip flies under phase 1, as it was meant to.
+  uint32_t p1_raw = 0, p1_nw = 0, p1_cs = 0;
+  {
+    const int item = wave;
+    if (item < G + 2) {
+      const int h = item == 0 ? H + kvh : (item == 1 ? H + KVH + kvh : kvh * Gt + gz * G + (item - 2));
+      const int p = lane < D / 2 ? lane : 0;
+      p1_raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+      if (item != 1) {
+        const bf16_t* nw = (item == 0) ? a.knw : a.qnw;
+        if (nw) p1_nw = *reinterpret_cast<const uint32_t*>(nw + 2 * p);
+        p1_cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+      }
+    }
+  }
+  // (unconditional: a wave without a first group re-reads token 0's rows and ignores them -- behind a branch the
+  // compiler cannot count the outstanding loads at the join and falls back to s_waitcnt vmcnt(0) before phase 1)
+  load_trip(wave);
 
   // ---- phase 1
   for (int item = wave; item < G + 2; item += NW) {
     const int h = item == 0 ? H + kvh : (item == 1 ? H + KVH + kvh : kvh * Gt + gz * G + (item - 2));
     const bool act = lane < D / 2;
     const int p = act ? lane : 0;
-    uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+    const bool first = item == wave;   // (the first -- for G <= 6 the only -- item of a wave was requested above)
+    uint32_t raw = first ? p1_raw : *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
     float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
     bf16_t o0 = (bf16_t)(raw & 0xffff), o1 = (bf16_t)(raw >> 16);
     if (item != 1) {
@@ -485,10 +506,11 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
       if (nw) {
         float ss = wave_sum(x0 * x0 + x1 * x1);
         float rstd = rsqrtf(ss / (float)D + a.eps);
-        y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(nw[2 * p])));
-        y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(nw[2 * p + 1])));
+        const uint32_t nwp = first ? p1_nw : *reinterpret_cast<const uint32_t*>(nw + 2 * p);
+        y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f((bf16_t)(nwp & 0xffff))));
+        y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f((bf16_t)(nwp >> 16))));
       }
-      uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+      uint32_t cs = first ? p1_cs : *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
       float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
       o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
       o1 = f2bf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
