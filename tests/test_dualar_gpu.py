@@ -1170,3 +1170,31 @@ def test_prefix_reuse_is_bit_identical_for_every_length_class():
     # 40 | +3 (40 reused) | +27 (43 reused) | 33 new | 9 new | +5 (9 reused, both short) | 30 new (short -> long) | 29 reused
     assert model.reused_rows == 40 + 43 + 9 + 29, model.reused_rows
     assert model.prefilled_rows == sum(p.shape[1] for p in seq) - model.reused_rows
+
+
+def test_prefill_attention_wide_query_tiles_equal_the_16_row_tiles_bit_for_bit():
+    """Round 4: from 2048 / 4096 rows per prefill call the MFMA prefill attention gives a work-group 32 / 48 query rows
+    (two / three column groups sharing the staged K/V blocks) instead of 16.  A query row's arithmetic does not depend
+    on the group it sits in: the first-frame logits and hidden rows of every utterance of a 9-prompt call (4.3 k rows:
+    48-row tiles), of its first 5 prompts (2.4 k rows: 32-row tiles) and of each prompt alone (16-row tiles) are equal
+    bit for bit -- which also pins the 256-column prefill GEMM's tile heights (chosen from the row count) against each other."""
+    cfg, state, _ = load_dualar_case("mid_peaky")
+    model = _make_model(cfg, state, max_batch=9)
+    prompts = [O.make_prompt(cfg, 500 - 7 * i, seed=50 + i, n_semantic=100) for i in range(9)]
+    assert sum(p.shape[1] for p in prompts) >= 4096 and 2048 <= sum(p.shape[1] for p in prompts[:5]) < 4096
+
+    def first_frame(idx):
+        sp = [model._sampling(0.7, 0.7, 1, 100 + i, True) for i in idx]
+        model.prefill(list(range(len(idx))), [prompts[i] for i in idx], [2] * len(idx), sp)
+        logits, _, hidden, _ = model.debug_taps(len(idx))
+        for s in range(len(idx)):
+            model.release(s)
+        return logits.cpu(), hidden.cpu()
+
+    l9, h9 = first_frame(list(range(9)))
+    l5, h5 = first_frame(list(range(5)))
+    assert torch.equal(l9[:5], l5) and torch.equal(h9[:5], h5)
+    for i in (0, 4, 8):
+        l1, h1 = first_frame([i])
+        assert torch.equal(l9[i : i + 1], l1) and torch.equal(h9[i : i + 1], h1), i
+    assert bool(torch.isfinite(l9[:, :8].float()).all())
