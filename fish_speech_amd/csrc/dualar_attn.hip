@@ -20,19 +20,25 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(AttnArgs a) {
   const bf16_t* src = a.qkv + (int64_t)r * total * D;
   const bool act = lane < D / 2;
   const int p = act ? lane : 0;
+  // the three operands of a head -- its slice of the q|k|v row, the norm weight pair, the RoPE pair -- are requested
+  // together (none of the addresses depends on another's data): they had been three dependent round trips per wave
+  const bf16_t* nw = (h < H) ? a.qnw : (h < H + KVH ? a.knw : nullptr);
   uint32_t raw = *reinterpret_cast<const uint32_t*>(src + h * D + 2 * p);
+  uint32_t nwp = 0, cs = 0;
+  if (h < H + KVH) {
+    if (nw) nwp = *reinterpret_cast<const uint32_t*>(nw + 2 * p);
+    cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
+  }
   float x0 = act ? bf2f((bf16_t)(raw & 0xffff)) : 0.f, x1 = act ? bf2f((bf16_t)(raw >> 16)) : 0.f;
   bf16_t o0 = (bf16_t)(raw & 0xffff), o1 = (bf16_t)(raw >> 16);
   if (h < H + KVH) {
-    const bf16_t* nw = (h < H) ? a.qnw : a.knw;
     float y0 = x0, y1 = x1;
     if (nw) {  // torch.nn.RMSNorm: fp32 normalise * weight, one cast (llama.py:862-864)
       float ss = wave_sum(x0 * x0 + x1 * x1);
       float rstd = rsqrtf(ss / (float)D + a.eps);
-      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(nw[2 * p])));
-      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(nw[2 * p + 1])));
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f((bf16_t)(nwp & 0xffff))));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f((bf16_t)(nwp >> 16))));
     }
-    uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
     float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
     // llama.py:1026-1038, separate fp32 mul / sub / add (no fused multiply-add)
     o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
