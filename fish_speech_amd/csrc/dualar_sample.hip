@@ -449,10 +449,15 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   // ---- pass 1: coalesced loads (element tid + 256 j), keys to LDS, block max
   float xv[SMALL_EPT];
   uint32_t kmax = 0;
+  // (all 17 loads requested before the first is used -- clamped index, then a select: behind the `i < n` branch each
+  // load had its own s_waitcnt vmcnt(0), seventeen dependent L2 round trips at the top of every sampler launch)
+  bf16_t lraw[SMALL_EPT];
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j) lraw[j] = lg[min(tid + 256 * j, n - 1)];
 #pragma unroll
   for (int j = 0; j < SMALL_EPT; ++j) {
     const int i = tid + 256 * j;
-    const bf16_t raw = i < n ? lg[i] : (bf16_t)0xff80;  // -inf padding
+    const bf16_t raw = i < n ? lraw[j] : (bf16_t)0xff80;  // -inf padding
     xv[j] = bf2f(raw);
     const uint32_t key = order_key(raw);
     if (i < n) {
