@@ -441,7 +441,7 @@ int launch_attn_prefill_mfma(const AttnArgs& a, hipStream_t s) {
 //   phase 2: tokens [0, pos) stream from the paged cache, 4 tokens per wave-load, 4 loads in flight per
 //            lane; token `pos` comes from LDS.  Online softmax per lane group, merged in-wave by
 //            shuffles, across waves through LDS.
-template <int D, int G>
+template <int D, int G, bool BTR>
 __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
   constexpr int NW = 8, LPT = D / 8, TPW = 64 / LPT, UN = 4;
   __shared__ float s_q[G][D];
@@ -456,6 +456,16 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
   const int H = a.H, KVH = a.KVH, Gt = H / KVH;
   const int32_t* bt = a.block_table + (int64_t)slot * a.max_pages;
   const bf16_t* src = a.qkv + (int64_t)r * (H + 2 * KVH) * D;
+  // the slot's block-table row (<= 64 pages = 4096 positions) in one register per wave: a token's page then comes from a
+  // lane of it (ds_bpermute) instead of a global load in front of every K/V trip -- one dependent L2 round trip less
+  // per trip.  Longer tables fall back to the loads.
+  // (BTR, chosen by the launcher: a run-time select between the two kept both, with a wait behind every load)
+  int btv = 0;
+  if constexpr (BTR) btv = bt[min(lane, a.max_pages - 1)];
+  auto page_of = [&](int pg) -> int {
+    if constexpr (BTR) return __shfl(btv, pg, 64);
+    else return bt[pg];
+  };
 
   // ---- prefetch: the first trip of cached K/V rows does not depend on q, so it is issued before the
   // norm/RoPE phase and its HBM latency overlaps that phase
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
       const int t = (g0 + u * NW) * TPW + sub;
       valid[u] = t < pos;
       const int tc = valid[u] ? t : 0;
-      const int page = bt[tc / KV_PAGE];
+      const int page = page_of(tc / KV_PAGE);
       const int64_t base = (((int64_t)page * KVH + kvh) * KV_PAGE + (tc % KV_PAGE)) * D + dl * 8;
       kv[u] = *reinterpret_cast<const uint4*>(a.kpool + base);
       vv[u] = *reinterpret_cast<const uint4*>(a.vpool + base);
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(AttnArgs a) {
         // every split recomputes the new k/v row for its LDS copy; one of them appends it -- unless the slot has
         // finished (its position no longer advances and may sit one past the pages it reserved)
         if (gz == 0 && !(a.slot_done && a.slot_done[slot])) {
-          const int page = bt[pos / KV_PAGE];
+          const int page = page_of(pos / KV_PAGE);
           bf16_t* pool = (item == 0) ? a.kpool : a.vpool;
           *reinterpret_cast<uint32_t*>(pool + (((int64_t)page * KVH + kvh) * KV_PAGE + pos % KV_PAGE) * D + 2 * p) =
               (uint32_t)o0 | ((uint32_t)o1 << 16);
@@ -967,12 +977,18 @@ static int launch_attn_decode_d(const AttnArgs& a, hipStream_t s) {
   if (Gt % split != 0) split = 1;
   const int G = Gt / split;
   dim3 grid(a.rows, a.KVH, split), block(512);
+#define FMI_DECODE(G_)                                                                                     \
+  do {                                                                                                      \
+    if (a.max_pages <= 64) hipLaunchKernelGGL((attn_decode_fused_kernel<D, G_, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((attn_decode_fused_kernel<D, G_, false>), grid, block, 0, s, a);                \
+  } while (0)
   switch (G) {
-    case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 1>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 2>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<D, 4>), grid, block, 0, s, a); break;
+    case 1: FMI_DECODE(1); break;
+    case 2: FMI_DECODE(2); break;
+    case 4: FMI_DECODE(4); break;
     default: return set_error(FMI_EINVAL, "attn: GQA ratio %d unsupported", Gt);
   }
+#undef FMI_DECODE
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -1039,6 +1055,12 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
   const int p = act ? lane : 0;
   uint32_t cs = *reinterpret_cast<const uint32_t*>(a.rope + ((int64_t)pos * (D / 2) + p) * 2);
   const float c = bf2f((bf16_t)(cs & 0xffff)), sn = bf2f((bf16_t)(cs >> 16));
+  // the q / k head-norm weight pairs of this lane, requested here with everything else that does not depend on the
+  // step's projections (loaded where they are used they were one more dependent L2 round trip per head)
+  const uint32_t knw_p = a.knw ? *reinterpret_cast<const uint32_t*>(a.knw + 2 * p) : 0u;
+  const uint32_t qnw_p = a.qnw ? *reinterpret_cast<const uint32_t*>(a.qnw + 2 * p) : 0u;
+  const float knw0 = bf2f((bf16_t)(knw_p & 0xffff)), knw1 = bf2f((bf16_t)(knw_p >> 16));
+  const float qnw0 = bf2f((bf16_t)(qnw_p & 0xffff)), qnw1 = bf2f((bf16_t)(qnw_p >> 16));
 
   // Requested up front (none of it depends on this step's projections): the cached key rows this lane scores,
   // the cached value elements it accumulates, and the first query head of this wave -- the kernel is a chain of
@@ -1062,8 +1084,8 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
     if (a.knw) {
       float ss = wave_sum_dpp(x0 * x0 + x1 * x1);
       float rstd = rsqrtf(ss / (float)D + a.eps);
-      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.knw[2 * p])));
-      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.knw[2 * p + 1])));
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), knw0));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), knw1));
     }
     bf16_t o0 = f2bf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
     bf16_t o1 = f2bf(__fadd_rn(__fmul_rn(y1, c), __fmul_rn(y0, sn)));
@@ -1088,8 +1110,8 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
     if (a.knw) {
       float ss = wave_sum_dpp(x0 * x0 + x1 * x1);
       float rstd = rsqrtf(ss / (float)D + a.eps);
-      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.knw[2 * p])));
-      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.knw[2 * p + 1])));
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), knw0));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), knw1));
     }
     bf16_t o0 = f2bf(__fsub_rn(__fmul_rn(y0, c0), __fmul_rn(y1, sn0)));
     bf16_t o1 = f2bf(__fadd_rn(__fmul_rn(y1, c0), __fmul_rn(y0, sn0)));
@@ -1114,8 +1136,8 @@ __global__ __launch_bounds__(256) void fast_attn_kernel(FastAttnArgs a) {
     if (a.qnw) {
       float ss = wave_sum_dpp(x0 * x0 + x1 * x1);
       float rstd = rsqrtf(ss / (float)D + a.eps);
-      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), bf2f(a.qnw[2 * p])));
-      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), bf2f(a.qnw[2 * p + 1])));
+      y0 = rbf(__fmul_rn(__fmul_rn(x0, rstd), qnw0));
+      y1 = rbf(__fmul_rn(__fmul_rn(x1, rstd), qnw1));
     }
     if (act) {
       s_q[wave][2 * p] = rbf(__fsub_rn(__fmul_rn(y0, c), __fmul_rn(y1, sn)));
