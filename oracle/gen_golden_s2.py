@@ -51,6 +51,10 @@ CASES = {
     "s2_sampled": (SAMPLED_STATE, (200, 60, range(1, 8)), 64, (0.7, 0.9, 30), range(int(os.environ.get("S2_USEED0", "6")), 200)),
     # round 4: the benchmark's full 215 frames (context 200 -> 415: all 7 KV pages of a 512-position slot), greedy
     "s2_plain215": (GREEDY_STATE, (200, 0, range(1, 40)), 215, (0.7, 0.7, 1), range(1234, 1260)),
+    # round 4: a 1010-token voice-clone-shaped prompt + 24 frames, greedy: the free run crosses position 1024, where decode
+    # attention moves to the MFMA split-K kernel + merge -- at the BASELINE width (G = 4, D = 128: the kernels the
+    # benchmark shape runs at long contexts), with a 1010-row prefill through the 256-column GEMM tiles
+    "s2_long": (GREEDY_STATE, (1010, 300, range(1, 12)), 24, (0.7, 0.7, 1), range(1234, 1240)),
     # round 4: sampled decisions that leave the top-1 candidate (S2_MIN_NON_TOP1, default 3 for this case)
     "s2_sampled2": (SAMPLED2_STATE, (200, 60, range(1, 8)), 64, (0.7, 0.9, 30), range(int(os.environ.get("S2_USEED0", "1")), 400)),
 }
@@ -105,7 +109,7 @@ def main(which):
     from .search_golden import sampled_frame_is_robust, sampled_run_is_robust
 
     torch.set_num_threads(8)
-    cfg = O.s2_pro_shaped_config(max_seq_len=512)
+    cfg = O.s2_pro_shaped_config(max_seq_len=2048 if "s2_long" in which else 512)
     ids = live_ids(cfg)
     states = {}
     orig_build = refload.build_reference_dual_ar

@@ -39,17 +39,17 @@ def _load(name):
 _models = {}
 
 
-def _model(skw):
+def _model(skw, max_seq_len=512, slots=8):
     """One HIP model per weight recipe (greedy cases share theirs), built on the device; kept for the module."""
     from fish_speech_amd.dual_ar import MiDualAR
 
-    key = json.dumps(skw, sort_keys=True)
+    key = json.dumps(skw, sort_keys=True) + f"|{max_seq_len}"
     if key not in _models:
-        ocfg = O.s2_pro_shaped_config(max_seq_len=512)
+        ocfg = O.s2_pro_shaped_config(max_seq_len=max_seq_len)
         state = O.make_peaky_state_hash(ocfg, device=DEV, **skw)
         m = MiDualAR(ocfg, device=DEV, im_end_id=ocfg.im_end_id)
         m.load_state_dict(state)
-        m.setup_caches(8, 512)
+        m.setup_caches(slots, max_seq_len)
         _models[key] = (ocfg, m, state)
     return _models[key]
 
@@ -256,3 +256,29 @@ def test_s2_serve_stream_two_staggered_requests_equal_the_fixtures_and_the_offli
         off = codec.from_indices(want[None].clone().to(DEV))[0, 0].cpu()
         assert torch.equal(audio, off), f"request {i}: streamed audio differs from the offline decode"
     codec.stream_reset()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "dualar_s2_long.npz")), reason="fixture not generated")
+def test_s2_long_prompt_crosses_the_mfma_decode_attention_threshold():
+    """dualar_s2_long.npz (round 4): the unmodified reference's generate() on the 4.56 B hash-weight model with a
+    1010-token voice-clone-shaped prompt, 24 greedy frames (every decision >= 16 bf16 steps of margin): frames from
+    position 1024 on run the decode attention on attn_decode_mfma_kernel + attn_decode_merge_kernel at the BASELINE
+    shape (G = 4, D = 128), the 1010-row prefill goes through the 256-column GEMM tiles and 16 KV pages.  The whole
+    (11, 1034) matrix equals the reference's -- with the MFMA pair, and with the VALU kernel for every row."""
+    from fish_speech_amd.dual_ar import generate
+
+    z, skw = _load("s2_long")
+    cfg, model, _ = _model(skw, max_seq_len=2048, slots=2)
+    want = z["tokens"]
+    T = z["prompt"].shape[1]
+    assert T < 1024 < want.shape[1]
+    kw = dict(prompt=torch.from_numpy(z["prompt"]), max_new_tokens=int(z["max_new"]), temperature=float(z["temperature"]),
+              top_p=float(z["top_p"]), top_k=int(z["top_k"]), seed=int(z["uniform_seed"]))
+    got = generate(model=model, **kw).numpy()
+    bad = np.argwhere(got != want) if got.shape == want.shape else None
+    assert got.shape == want.shape and len(bad) == 0, f"first mismatch at {None if bad is None else bad[0].tolist()}"
+    model.set_attn_long_threshold(0)
+    got2 = generate(model=model, **kw).numpy()
+    model.set_attn_long_threshold(1024)
+    assert np.array_equal(got2, want), "VALU decode attention for every row differs"
+    print("s2_long full sequence equal;", str(z["note"]))
