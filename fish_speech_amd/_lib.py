@@ -95,6 +95,7 @@ _SIGS = {
     "fmi_dac_decode_tail": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "fmi_dac_decode_tail_cached": (C.c_int, [_P, _P, _I, _I, _I, C.c_int64, _P, _P]),
     "fmi_dac_stream_reset": (C.c_int, [_P]),
+    "fmi_dac_stream_close": (C.c_int, [_P, C.c_int64]),
     "fmi_dac_context_frames": (C.c_int, [_P]),
     "fmi_dac_encode": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "fmi_dac_frame_length": (C.c_int, [_P]),

@@ -1009,6 +1009,25 @@ int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, i
   return sync_out(h, stream);
 }
 
+int fmi_dac_stream_close(fmi_dac* h, int64_t stream_id) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h, "null handle");
+  if (h->st.id == stream_id && h->st.T > 0) {   // the active state: its buffers stay for the next stream, its content is void
+    h->st.T = 0;
+    h->st.id = 0;
+    return FMI_OK;
+  }
+  for (size_t i = 0; i < h->parked.size(); ++i)
+    if (h->parked[i].id == stream_id) {
+      FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+      free_one_state(h->parked[i]);
+      h->parked.erase(h->parked.begin() + i);
+      break;
+    }
+  return FMI_OK;   // (an unknown id is not an error: the state may have been dropped as least recently used)
+}
+
 int fmi_dac_stream_reset(fmi_dac* h) {
   std::unique_lock<std::mutex> lock_;
   if (h) lock_ = std::unique_lock<std::mutex>(h->mu);

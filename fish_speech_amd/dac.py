@@ -493,6 +493,11 @@ class MiDAC:
         """free the device state kept for from_indices_tail(stream_id=...)"""
         check(self.lib.fmi_dac_stream_reset(self._h))
 
+    def close_stream(self, stream_id: int) -> None:
+        """The stream `stream_id` has ended: drop its incremental state now (fmi_dac_stream_close) instead of letting it
+        age out of the 16 kept states."""
+        check(self.lib.fmi_dac_stream_close(self._h, int(stream_id)))
+
     @property
     def context_frames(self) -> int:
         """left context (frames) the decoder conv stack re-reads per incremental call"""

@@ -190,6 +190,7 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
                 u = live.pop(s_)
                 yield StreamEvent(u.req.rid, "final", 0, u.emitted, None, None, clock() - start)
                 model.release(s_)
+                _close_stream(codec, u.stream_id)
                 free.append(s_)
             if not live:
                 continue
@@ -238,6 +239,7 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
                 if ended:
                     yield StreamEvent(u.req.rid, "final", 0, u.emitted, None, None, clock() - start)
                     model.release(s)
+                    _close_stream(codec, u.stream_id)
                     del live[s]
                     free.append(s)
 
@@ -245,9 +247,17 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
         for s_ in list(live):
             try:
                 model.release(s_)
+                _close_stream(codec, live[s_].stream_id)
             except Exception:                # noqa: BLE001
                 pass
             live.pop(s_, None)
+
+def _close_stream(codec, stream_id) -> None:
+    """An utterance's codec stream has ended: its incremental state goes now (MiDAC.close_stream), not by LRU ageing."""
+    close = getattr(codec, "close_stream", None)
+    if close is not None and stream_id:
+        close(stream_id)
+
 
 def collect(events: Iterable[StreamEvent], frame_length: int):
     """Concatenate every utterance's segments: {rid: (audio (n * frame_length,) fp32 CPU, codes (ncb, n) CPU)}."""

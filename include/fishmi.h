@@ -297,6 +297,10 @@ int fmi_dac_context_frames(const fmi_dac* h);
 int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, int64_t stream_id,
                                float* audio_out_dev, void* stream);
 int fmi_dac_stream_reset(fmi_dac* h);
+/* An utterance's stream has ended (or was cancelled): drop the state kept under `stream_id` now instead of waiting for it
+ * to fall out as least recently used (a serving loop opens a stream per utterance; 16 states are kept).  Unknown ids are
+ * ignored. */
+int fmi_dac_stream_close(fmi_dac* h, int64_t stream_id);
 /* DAC.decode (modded_dac.py:929-946): latent z fp32 (B, latent_dim, L) -> audio fp32 (B,1,L*hop_length). */
 int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* audio_out_dev, void* stream);
 /* DAC.encode (modded_dac.py:874-923): audio fp32 (B,1,N) (N already padded to a multiple of
