@@ -234,6 +234,8 @@ class BatchingTTSEngine(StreamingTTSEngine):
                 ev = q.get(timeout=self.result_timeout)
                 if isinstance(ev, Exception):
                     raise ev
+                if ev.kind == "error":       # this request alone was refused at admission (serving.serve_stream)
+                    raise ValueError(ev.error)
                 if ev.kind == "final":
                     return
                 yield ev

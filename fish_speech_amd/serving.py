@@ -87,13 +87,14 @@ class RequestFeed:
 @dataclass
 class StreamEvent:
     rid: int
-    kind: str                                # "segment" | "final"
+    kind: str                                # "segment" | "final" | "error"
     t0: int                                  # first frame of the segment
     t1: int                                  # one past its last frame
     audio: Optional[torch.Tensor]            # (1, 1, (t1 - t0) * frame_length) fp32 on the device ("segment")
     codes: Optional[torch.Tensor]            # (num_codebooks, t1 - t0) int64 on the device ("segment")
     t_emit: float                            # seconds since the loop started
     first_audio_latency: Optional[float] = None   # on an utterance's first segment: t_emit - max(arrival, 0)
+    error: Optional[str] = None                   # kind "error": why this request was not admitted (feed-driven loops only)
 
 
 @dataclass
@@ -163,18 +164,31 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
         while True:
             # ---- admission: every arrived request that finds a free slot is prefilled in ONE call
             new: List[_Live] = []
+            samp = []
             while free and next_request() is not None and clock() - start >= pending.arrival:
                 r, pending = pending, None
-                T = r.prompt.size(1)
-                if T >= cfg.max_seq_len:  # inference.py:263-266
-                    raise ValueError(f"Input sequence length {T} exceeds max_seq_len {cfg.max_seq_len}")
-                limit = min(r.max_new_tokens if r.max_new_tokens else cfg.max_seq_len - T, cfg.max_seq_len - T)
-                marks = chunk_schedule(limit, opt(r.first_chunk_frames, first_chunk_frames), opt(r.chunk_frames, chunk_frames),
-                                       opt(r.chunk_growth, chunk_growth), opt(r.max_chunk_frames, max_chunk_frames))
+                # a request is validated BEFORE it joins the prefill call.  From a list of requests a bad one raises (the
+                # caller's bug); from a feed it fails alone -- an "error" event for its owner, the loop and everybody
+                # else's utterances go on (one bad request used to end the loop for all of them)
+                try:
+                    T = r.prompt.size(1)
+                    if r.prompt.dim() != 2 or r.prompt.size(0) != cfg.num_codebooks + 1:
+                        raise ValueError(f"prompt must be ({cfg.num_codebooks + 1}, T), got {tuple(r.prompt.shape)}")
+                    if T >= cfg.max_seq_len:  # inference.py:263-266
+                        raise ValueError(f"Input sequence length {T} exceeds max_seq_len {cfg.max_seq_len}")
+                    limit = min(r.max_new_tokens if r.max_new_tokens else cfg.max_seq_len - T, cfg.max_seq_len - T)
+                    marks = chunk_schedule(limit, opt(r.first_chunk_frames, first_chunk_frames), opt(r.chunk_frames, chunk_frames),
+                                           opt(r.chunk_growth, chunk_growth), opt(r.max_chunk_frames, max_chunk_frames))
+                    sp = model._sampling(opt(r.temperature, temperature), opt(r.top_p, top_p), opt(r.top_k, top_k),
+                                         r.seed if r.seed is not None else model.next_seed(), use_ras)
+                except (ValueError, TypeError) as e:
+                    if feed is None:
+                        raise
+                    yield StreamEvent(r.rid, "error", 0, 0, None, None, clock() - start, error=str(e))
+                    continue
                 new.append(_Live(r, free.pop(), limit, marks, stream_id=codec.new_stream_id()))
+                samp.append(sp)
             if new:
-                samp = [model._sampling(opt(u.req.temperature, temperature), opt(u.req.top_p, top_p), opt(u.req.top_k, top_k),
-                                        u.req.seed if u.req.seed is not None else model.next_seed(), use_ras) for u in new]
                 model.prefill([u.slot for u in new], [u.req.prompt for u in new], [u.limit for u in new], samp)
                 live.update({u.slot: u for u in new})
             if not live:

@@ -406,6 +406,31 @@ def test_serve_stream_over_a_request_feed_per_request_parameters_and_cancellatio
         feed2.put(a)
 
 
+def test_serve_stream_feed_a_bad_request_fails_alone():
+    """from a RequestFeed (a server) a request that cannot be admitted -- a prompt as long as the cache, a
+    malformed prompt -- gets an "error" event of its own; the loop and the other requests' utterances go on.  From a
+    plain list (a batch caller) the same request raises, as before."""
+    from fish_speech_amd.serving import RequestFeed, StreamRequest, collect, serve_stream
+
+    model, codec = StubDualAR(max_batch=2, max_seq_len=64), StubCodec()
+    good = StreamRequest(prompt=torch.zeros(NCB + 1, 5, dtype=torch.int64), seed=11, rid=1, max_new_tokens=6)
+    too_long = StreamRequest(prompt=torch.zeros(NCB + 1, 64, dtype=torch.int64), seed=3, rid=2)
+    malformed = StreamRequest(prompt=torch.zeros(NCB, 5, dtype=torch.int64), seed=4, rid=3)
+    other = StreamRequest(prompt=torch.zeros(NCB + 1, 7, dtype=torch.int64), seed=5, rid=4, max_new_tokens=6)
+    feed = RequestFeed()
+    for r in (good, too_long, malformed, other):
+        feed.put(r)
+    evs = list(serve_stream(model=model, codec=codec, requests=feed, max_batch=2, step_frames=4, return_when_idle=True))
+    errs = {e.rid: e.error for e in evs if e.kind == "error"}
+    assert set(errs) == {2, 3} and "exceeds max_seq_len" in errs[2] and "prompt must be" in errs[3]
+    assert sorted(e.rid for e in evs if e.kind == "final") == [1, 4] and not model.slots
+    got = collect(evs, codec.frame_length)
+    assert torch.equal(got[1][1], model.expected_codes(11, 6)) and torch.equal(got[4][1], model.expected_codes(5, 6))
+    with pytest.raises(ValueError, match="exceeds max_seq_len"):
+        list(serve_stream(model=model, codec=codec, requests=[good, too_long], max_batch=2))
+    assert not model.slots
+
+
 @pytest.mark.timeout(60)
 def test_engine_lock_excludes_interleaved_generators_and_may_be_released_by_another_thread():
     """`inference()` holds the model's lock across yields.  (a) Two requests interleaved on ONE thread must
