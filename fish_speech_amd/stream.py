@@ -131,6 +131,11 @@ def generate_stream(*, model: MiDualAR, codec: MiDAC, prompts: Sequence[torch.Te
             if all(finished):
                 break
     finally:
+        # the codec's incremental state of this stream is void now: closed, its buffers serve the next stream (left to
+        # age out of the 16 kept states, every new stream allocated ~1 GB of state before its first chunk)
+        close = getattr(codec, "close_stream", None)
+        if close is not None:
+            close(stream_id)
         if not reuse_prefix:
             for i in slots:
                 model.release(i)
