@@ -636,3 +636,42 @@ def test_reusable_prefix_rules():
     assert m._reusable_prefix(0, base[:, :14]) == 9               # both short
     assert m._reusable_prefix(0, base[:, :30]) == 0               # short cached, long new
     assert m._reusable_prefix(0, base[:, :1]) == 0                # a single column always runs
+
+
+def test_from_indices_ragged_groups_by_length_pads_at_the_end_and_keeps_the_callers_order():
+    """MiDAC.from_indices_ragged's host logic on a stand-in codec (the GPU test checks the audio bit for bit): utterances
+    are grouped by length, at most `max_group` per call, a group's padding bounded by `pad_waste`, every utterance's
+    codes reach the decoder unchanged in front of the padding, results come back in the caller's order, an empty
+    utterance yields an empty waveform without a call."""
+    from types import SimpleNamespace
+
+    from fish_speech_amd.dac import MiDAC
+
+    calls = []
+
+    class Fake:
+        config = SimpleNamespace(n_codebooks=3)
+        device = torch.device("cpu")
+        frame_length = 4
+        module_dtype = torch.float32
+
+        def from_indices(self, batch):
+            calls.append(tuple(batch.shape))
+            # "audio" = the first codebook's code of every frame, repeated frame_length times: recognisable per utterance
+            return batch[:, :1, :].float().repeat_interleave(self.frame_length, dim=2)
+
+    lens = [9, 1, 30, 10, 0, 29, 9, 3]
+    codes = [torch.full((4, t), 100 + i, dtype=torch.int64) for i, t in enumerate(lens)]
+    out = MiDAC.from_indices_ragged(Fake(), codes, max_group=3, pad_waste=0.35)
+    assert len(out) == len(lens)
+    for i, t in enumerate(lens):
+        assert out[i].shape == (1, 1, 4 * t)
+        assert t == 0 or bool((out[i] == 100 + i).all())            # its own codes, none of the padding's zeros
+    assert all(b <= 3 for b, _, _ in calls)
+    # (30, 29, 10): 21 padded frames <= 0.35 x 69 real ones | (9, 9, 3): 6 <= 0.35 x 21 | a 4th member would exceed max_group | (1)
+    assert sorted(calls) == sorted([(3, 4, 30), (3, 4, 9), (1, 4, 1)]), calls
+    calls.clear()
+    MiDAC.from_indices_ragged(Fake(), codes, max_group=8, pad_waste=0.0)      # no padding allowed: equal lengths only
+    assert sorted(calls) == sorted([(1, 4, 30), (1, 4, 29), (1, 4, 10), (2, 4, 9), (1, 4, 3), (1, 4, 1)]), calls
+    with pytest.raises(ValueError):
+        MiDAC.from_indices_ragged(Fake(), [torch.zeros(5, 7, dtype=torch.int64)])
