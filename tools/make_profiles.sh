@@ -71,6 +71,6 @@ want stream && python tools/stream_breakdown.py > "$OUT/${TAG}_stream_breakdown.
 want stream && python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt" 2>&1
 # prefill GEMM variants per shape (tools/gemm_bench.hip; the binary is built on the authoring side: see the file's header)
 if want gemm && [ -x tools/bin/gemm_bench ]; then
-{ echo "# tools/bin/gemm_bench lwx on MI355X (libfishmi.so sha1 $SHA, tree $HEAD): l = 4-wave LDS-staged, w = wave-specialised 128x128 (shipped), x = 128x256 three-stage tile"; tools/bin/gemm_bench lwx; } > "$OUT/${TAG}_gemm_bench.txt" 2>&1
+{ echo "# tools/bin/gemm_bench wxptsu on MI355X (libfishmi.so sha1 $SHA, tree $HEAD): w = wave-specialised 128x128 (round 3), x = 128x256 three-stage tile (round 3), p / u / s / t = linear_tiled_256p_kernel with 256 / 192 / 128 / 64-row tiles (round 4: what launch_linear_tiled chooses among); every variant checked bit for bit against the 4-wave LDS-staged kernel"; tools/bin/gemm_bench wxptsu; } > "$OUT/${TAG}_gemm_bench.txt" 2>&1
 fi
 ls -la "$OUT"
