@@ -155,6 +155,40 @@ def synthetic_codec_state(cfg, device, seed=1):
     return st
 
 
+def construct(cfg, device, rank, int8=False, with_codec=True, replicate=None):
+    """The objects of one rank, in the order every rank of an N-GPU job builds them: handle over an empty arena; rank 0
+    alone generates / loads the weights (a checkpoint is read once per node); `replicate(obj)` (dist.broadcast_arena)
+    puts the arena content in place on the other ranks and marks it ready there -- those ranks never see load_tensor or
+    finalize, their derived tables (fast layer-0 q|k|v, row-balanced copies) are rebuilt from the received bytes by the
+    first prefill.  Returns (model, codec, state, codec_state); the states are None on ranks > 0.
+    tests/test_rank_gpu.py runs this with rank = 1 inside the 1-GPU lease."""
+    from fish_speech_amd.dual_ar import MiDualAR
+
+    model = MiDualAR(cfg, device=device, im_end_id=cfg.im_end_id)
+    state = None
+    if rank == 0:
+        state = synthetic_state_on_device(cfg, device)
+        model.load_state_dict(quantize_state_int8_on_device(state) if int8 else state)
+    if replicate is not None:
+        replicate(model)
+    # 1024 positions per slot: covers config 3's 400 + 430.  Sixteen slots (the handle's caches are set up once): the timed
+    # region runs 8 utterances in 8 of them, other_configs.batch16 all sixteen
+    model.setup_caches(2 * BATCH, cfg.max_seq_len)
+    model.set_ignore_eos(True)
+    codec, codec_state = None, None
+    if with_codec:
+        from fish_speech_amd.dac import DacConfig, MiDAC
+
+        ccfg = DacConfig()
+        codec = MiDAC(ccfg, device=device)
+        if rank == 0:
+            codec_state = synthetic_codec_state(ccfg, device)
+            codec.load_folded_state(codec_state)
+        if replicate is not None:
+            replicate(codec)
+    return model, codec, state, codec_state
+
+
 def run_step(model, codec, prompts, samp_seeds, device):
     """One pass of the hot path over one batch: prefill + 214 graph-replayed decode frames + codec decode
     of the generated codes (rows 1.. of each frame; the last frame is dropped like generate_long does,
@@ -165,6 +199,34 @@ def run_step(model, codec, prompts, samp_seeds, device):
                                   temperature=0.7, top_p=0.7, top_k=30)   # (B, ncb, N_FRAMES) int64 on device
     wav = codec.from_indices(codes) if codec is not None else None
     return codes, wav
+
+
+def run_steps_overlapped(model, codec, prompts, samp_seeds, device, steps, side):
+    """`steps` passes of the hot path with the two halves of a step overlapped ACROSS steps: while the HBM-bound frame
+    loop of batch i replays on the model's stream, the MFMA-bound codec decode of batch i - 1 runs on the codec's own
+    stream (`codec.set_async(True)`: no cross-queue wait is left pending).  Every step's prefill, 214 frames and codec
+    decode happen inside the call; the last batch's decode is not overlapped with anything.  Returns (per-step decode
+    frame ms, the last batch's waveform).  `side`: a torch stream the codec's buffers are allocated on."""
+    from fish_speech_amd.dual_ar import finish_batch_device, generate_batch_device
+
+    frame_ms, pending, wav, keep = [], None, None, []
+    for _ in range(steps):
+        tok = generate_batch_device(model=model, prompts=prompts, max_new_tokens=N_FRAMES, seeds=samp_seeds,
+                                    temperature=0.7, top_p=0.7, top_k=30, wait=False)    # enqueued, host free
+        if pending is not None:
+            codec.synchronize()                                     # (the previous decode's buffers may be recycled now)
+            side.wait_stream(torch.cuda.current_stream(device))     # the codes were copied out on the current stream
+            with torch.cuda.stream(side):
+                wav = codec.from_indices(pending)
+            keep = [pending, wav]                                   # alive until the codec stream is done with them
+        pending = finish_batch_device(model, tok)                   # host waits for the frames here
+        ms, _ = model.last_decode_stats()
+        frame_ms.append(ms / max(N_FRAMES - 1, 1))
+    codec.synchronize()
+    wav = codec.from_indices(pending)
+    codec.synchronize()
+    del keep
+    return frame_ms, wav
 
 
 def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=32, codec_frames=N_FRAMES):
@@ -578,32 +640,13 @@ def main():
     globals()["N_FRAMES"] = args.frames
     cfg = s2_pro_config()
     cfg.weight_int8 = bool(args.int8)
-    model = MiDualAR(cfg, device=device, im_end_id=cfg.im_end_id)
-    state = None
-    if rank == 0:
-        state = synthetic_state_on_device(cfg, device)
-        model.load_state_dict(quantize_state_int8_on_device(state) if args.int8 else state)
-    if dist:  # the only collective of the path: one broadcast of the packed weight arena (xGMI)
+    replicate = None
+    if dist:  # the only collective of the path: one broadcast of each packed weight arena (xGMI)
         from fish_speech_amd.dist import broadcast_arena
 
-        broadcast_arena(model, src=0)
-    # 1024 positions per slot: covers config 3's 400 + 430.  Sixteen slots (the handle's caches are set up once): the timed
-    # region runs 8 utterances in 8 of them, other_configs.batch16 all sixteen
-    model.setup_caches(2 * BATCH, cfg.max_seq_len)
-    model.set_ignore_eos(True)
-    codec, codec_state = None, None
-    if not args.no_codec:
-        from fish_speech_amd.dac import DacConfig, MiDAC
-
-        ccfg = DacConfig()
-        codec = MiDAC(ccfg, device=device)
-        if rank == 0:
-            codec_state = synthetic_codec_state(ccfg, device)
-            codec.load_folded_state(codec_state)
-        if dist:
-            from fish_speech_amd.dist import broadcast_arena
-
-            broadcast_arena(codec, src=0)
+        replicate = lambda m: broadcast_arena(m, src=0)   # noqa: E731
+    model, codec, state, codec_state = construct(cfg, device, rank, int8=args.int8, with_codec=not args.no_codec,
+                                                 replicate=replicate)
     if args.no_graph:
         model.set_graph(False)
     prompts = make_prompts(cfg, BATCH, 1000 + rank * BATCH)

@@ -70,12 +70,14 @@ _SIGS = {
     "fmi_dualar_forward_slow": (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P]),
     "fmi_dualar_forward_fast": (C.c_int, [_P, _I, _P, _I, _P, _P]),
     "fmi_dualar_table_ptr": (C.c_int, [_P, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I)]),
+    "fmi_dualar_derived_info": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "fmi_dualar_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_P),
                                         C.POINTER(_P), C.POINTER(_P)]),
     "fmi_dualar_set_trace": (C.c_int, [_P, _I, C.POINTER(_P)]),
     "fmi_dualar_set_graph": (C.c_int, [_P, _I]),
     "fmi_dualar_set_attn_impl": (C.c_int, [_P, _I]),
     "fmi_dualar_set_fast_merge": (C.c_int, [_P, _I]),
+    "fmi_dualar_set_stream_priority": (C.c_int, [_P, _I]),
     "fmi_dualar_set_attn_long_threshold": (C.c_int, [_P, _I]),
     "fmi_dualar_set_ignore_eos": (C.c_int, [_P, _I]),
     "fmi_dualar_last_decode_stats": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
@@ -89,6 +91,10 @@ _SIGS = {
     "fmi_dac_finalize_weights": (C.c_int, [_P, _P]),
     "fmi_dac_weights_ready": (C.c_int, [_P]),
     "fmi_dac_set_precision": (C.c_int, [_P, _I]),
+    "fmi_dac_set_async": (C.c_int, [_P, _I]),
+    "fmi_dac_wait": (C.c_int, [_P, _P]),
+    "fmi_dac_synchronize": (C.c_int, [_P]),
+    "fmi_dac_set_stream_options": (C.c_int, [_P, _I, _I, C.POINTER(C.c_uint32)]),
     "fmi_dac_fp16_overflow": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "fmi_dac_decode": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "fmi_dac_decode_latent": (C.c_int, [_P, _P, _I, _I, _P, _P]),

@@ -108,6 +108,8 @@ struct fmi_dac {
   // runtime
   hipStream_t stream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  bool async_out = false;   // fmi_dac_set_async
+  int* f16_ovf = nullptr;   // device word: an operand of the fp16-split arithmetic left the fp16 range (fmi_dac_fp16_overflow)
   Buf buf[6];
   void* staging = nullptr;
   size_t staging_bytes = 0;
@@ -378,6 +380,7 @@ int ensure_buf(fmi_dac* h, int i, int64_t n) {
 }
 
 int sync_in(fmi_dac* h, void* us) {
+  set_f16_overflow_target(h->f16_ovf);   // every entry point comes through here, under h->mu: its kernels flag THIS handle
   FMI_CHECK_HIP(hipEventRecord(h->ev_in, (hipStream_t)us));
   FMI_CHECK_HIP(hipStreamWaitEvent(h->stream, h->ev_in, 0));
   return FMI_OK;
@@ -385,6 +388,14 @@ int sync_in(fmi_dac* h, void* us) {
 int sync_out(fmi_dac* h, void* us) {
   FMI_CHECK_HIP(hipEventRecord(h->ev_out, h->stream));
   FMI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)us, h->ev_out, 0));
+  return FMI_OK;
+}
+// encode / decode entry points: with fmi_dac_set_async(h, 1) the caller's stream is NOT made to wait for the call (it
+// orders itself with fmi_dac_wait or waits with fmi_dac_synchronize) -- a codec call that runs beside the Dual-AR frame
+// loop must not leave a cross-queue wait pending for its whole length (fishmi.h: fmi_dualar_decode, +0.3 ms per frame)
+int sync_out_data(fmi_dac* h, void* us) {
+  if (!h->async_out) return sync_out(h, us);
+  FMI_CHECK_HIP(hipEventRecord(h->ev_out, h->stream));
   return FMI_OK;
 }
 
@@ -774,7 +785,8 @@ int fmi_dac_create(const fmi_dac_config* cfg, void* arena_dev, int64_t arena_byt
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
+      hipMalloc((void**)&h->f16_ovf, sizeof(int)) != hipSuccess || hipMemset(h->f16_ovf, 0, sizeof(int)) != hipSuccess) {
     delete h;
     return set_error(FMI_EHIP, "stream/event creation failed (no GPU?)");
   }
@@ -793,6 +805,8 @@ void fmi_dac_destroy(fmi_dac* h) {
   for (auto p : h->pbuf)
     if (p) hipFree(p);
   free_all_stream_states(h);
+  set_f16_overflow_target(nullptr);   // (this thread's launch wrappers must not keep pointing at the freed word)
+  if (h->f16_ovf) hipFree(h->f16_ovf);
   hipEventDestroy(h->ev_in);
   hipEventDestroy(h->ev_out);
   hipStreamDestroy(h->stream);
@@ -914,7 +928,53 @@ int fmi_dac_fp16_overflow(fmi_dac* h, int* overflowed) {
   std::unique_lock<std::mutex> lock_;
   if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h && overflowed, "null argument");
-  return read_clear_f16_overflow(overflowed, h->stream);
+  return read_clear_f16_overflow(h->f16_ovf, overflowed, h->stream);
+}
+
+int fmi_dac_set_async(fmi_dac* h, int enable) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h, "null handle");
+  h->async_out = enable != 0;
+  return FMI_OK;
+}
+
+int fmi_dac_wait(fmi_dac* h, void* stream) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_out, 0));
+  return FMI_OK;
+}
+
+int fmi_dac_synchronize(fmi_dac* h) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  return FMI_OK;
+}
+
+// The handle's private stream re-created with a dispatch priority and / or a CU mask: a codec call that runs BESIDE the
+// Dual-AR frame loop can be kept off most of the chip (mask) or behind the loop's launches (priority).
+int fmi_dac_set_stream_options(fmi_dac* h, int priority, int cu_mask_words, const uint32_t* cu_mask) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h, "null handle");
+  FMI_REQUIRE(cu_mask_words >= 0 && (cu_mask_words == 0 || cu_mask), "bad CU mask");
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  hipStream_t ns = nullptr;
+  if (cu_mask_words > 0) {
+    FMI_CHECK_HIP(hipExtStreamCreateWithCUMask(&ns, (uint32_t)cu_mask_words, cu_mask));
+  } else {
+    int lo = 0, hi = 0;   // lo = least priority (numerically greatest), hi = greatest
+    FMI_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int pr = priority < 0 ? hi : (priority > 0 ? lo : (lo + hi) / 2);
+    FMI_CHECK_HIP(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, pr));
+  }
+  hipStreamDestroy(h->stream);
+  h->stream = ns;
+  return FMI_OK;
 }
 
 int fmi_dac_weights_ready(fmi_dac* h) {
@@ -935,7 +995,7 @@ int fmi_dac_decode(fmi_dac* h, int64_t* indices_dev, int B, int T, float* audio_
   int len;
   FMI_CHECK(run_quantizer_decode(h, indices_dev, B, T, &X, &Y, &len));
   FMI_CHECK(run_decoder(h, X, Y, B, len, audio_out_dev));
-  return sync_out(h, stream);
+  return sync_out_data(h, stream);
 }
 
 int fmi_dac_context_frames(const fmi_dac* h) { return h ? cdiv(decoder_context_cols(h->cfg), 4) : 0; }
@@ -962,7 +1022,7 @@ int fmi_dac_decode_tail(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, 
   FMI_CHECK_HIP(hipMemcpy2DAsync(X, (size_t)w * 4, h->buf[5].p + col_lo, (size_t)len * 4, (size_t)w * 4,
                                  (size_t)B * L0, hipMemcpyDeviceToDevice, s));
   FMI_CHECK(run_decoder(h, X, Y, B, w, audio_out_dev, 4 * ctx_frames));
-  return sync_out(h, stream);
+  return sync_out_data(h, stream);
 }
 
 int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, int t0, int64_t stream_id,
@@ -1006,7 +1066,7 @@ int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, i
   h->st.T = T;
   h->st.id = stream_id;
   h->st.planes = h->cur_planes;
-  return sync_out(h, stream);
+  return sync_out_data(h, stream);
 }
 
 int fmi_dac_stream_close(fmi_dac* h, int64_t stream_id) {
@@ -1052,7 +1112,7 @@ int fmi_dac_decode_latent(fmi_dac* h, const float* z_dev, int B, int L, float* a
   FMI_CHECK(ensure_buf(h, 1, peak));
   FMI_CHECK_HIP(hipMemcpyAsync(h->buf[0].p, z_dev, (size_t)B * c.latent_dim * L * 4, hipMemcpyDeviceToDevice, h->stream));
   FMI_CHECK(run_decoder(h, h->buf[0].p, h->buf[1].p, B, L, audio_out_dev));
-  return sync_out(h, stream);
+  return sync_out_data(h, stream);
 }
 
 int fmi_dac_debug_z(fmi_dac* h, float** z_dev, int* C, int* L) {
@@ -1123,7 +1183,7 @@ int fmi_dac_encode(fmi_dac* h, const float* audio_dev, int B, int N, int64_t* in
   };
   FMI_CHECK(step(h->sem, 0));
   for (int i = 0; i < c.n_codebooks; ++i) FMI_CHECK(step(h->rvq[i], i + 1));
-  return sync_out(h, stream);
+  return sync_out_data(h, stream);
 }
 
 }  // extern "C"

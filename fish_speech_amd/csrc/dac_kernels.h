@@ -52,6 +52,9 @@ struct ConvArgs {
   const bf16_t* xp;
   bf16_t* outp;
   const float* next_alpha;
+  // device word raised when an operand of the fp16 split leaves the fp16 range (owned by the codec handle);
+  // nullptr = the one named by set_f16_overflow_target() on this host thread
+  int* ovf;
 };
 // out[b][co][q*out_stride + phase] = res + gamma * act(bias + sum_ci sum_tap w[phase][tap][ci][co] *
 //                                    snake(x)[b][ci][q*x_stride + tap_base + tap*tap_step])
@@ -112,7 +115,10 @@ struct VqArgs {
 };
 int launch_vq_step(const VqArgs& a, hipStream_t s);
 
-// sticky fp16-split overflow flag (dac_kernels.hip: g_f16_overflow): waits for `s`, returns the flag and clears it
-int read_clear_f16_overflow(int* flag, hipStream_t s);
+// Sticky fp16-split overflow flag, one device word per codec handle.  set_f16_overflow_target names the word the launch
+// wrappers of THIS host thread hand to their kernels (an entry point sets it under its handle's mutex; nullptr = a
+// process-wide word nobody reads); read_clear waits for `s`, returns the word and clears it.
+void set_f16_overflow_target(int* dev_word);
+int read_clear_f16_overflow(int* dev_word, int* flag, hipStream_t s);
 
 }  // namespace fmi

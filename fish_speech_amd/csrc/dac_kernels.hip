@@ -308,12 +308,27 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float F16_LO_SCALE = 2048.0f;
 constexpr float F16_MAX = 65504.0f;
-// Sticky: set when a value outside the fp16 range reached the split (fmi_dac_fp16_overflow reads and clears it).  The
-// split SATURATES there (both terms clamped to the largest finite fp16, one v_med3_f32 each) instead of producing
-// inf - inf = NaN that would spread through the whole waveform; the caller can then redo the call with precision 0.
-__device__ int g_f16_overflow = 0;
-__device__ inline void split2_f16_pk(float x0, float x1, uint32_t& h, uint32_t& l) {
-  if (fmaxf(fabsf(x0), fabsf(x1)) > F16_MAX) g_f16_overflow = 1;
+// Sticky: *ovf is set when a value outside the fp16 range reached the split (fmi_dac_fp16_overflow reads and clears
+// it).  The split SATURATES there (both terms clamped to the largest finite fp16, one v_med3_f32 each) instead of
+// producing inf - inf = NaN that would spread through the whole waveform; the caller can then redo the call with
+// precision 0.  The word belongs to the codec HANDLE whose entry point launched the kernel (round 5; a process-wide flag
+// let two handles, or two request threads on two handles, consume each other's overflow): the entry point names it with
+// set_f16_overflow_target() under the handle's mutex, the launch wrappers below pass it on.  Launches outside any
+// entry point (tools/, benches) raise g_f16_overflow_unowned.
+__device__ int g_f16_overflow_unowned = 0;
+static thread_local int* t_f16_ovf = nullptr;
+void set_f16_overflow_target(int* dev_word) { t_f16_ovf = dev_word; }
+static int* f16_overflow_target() {
+  if (t_f16_ovf) return t_f16_ovf;
+  static int* unowned = []() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_f16_overflow_unowned)) != hipSuccess) p = nullptr;
+    return (int*)p;
+  }();
+  return unowned;
+}
+__device__ inline void split2_f16_pk(float x0, float x1, uint32_t& h, uint32_t& l, int* __restrict__ ovf) {
+  if (fmaxf(fabsf(x0), fabsf(x1)) > F16_MAX) *ovf = 1;
   x0 = __builtin_amdgcn_fmed3f(x0, -F16_MAX, F16_MAX);
   x1 = __builtin_amdgcn_fmed3f(x1, -F16_MAX, F16_MAX);
   const f16x2 hv = {(_Float16)x0, (_Float16)x1};
@@ -330,7 +345,7 @@ __host__ __device__ inline int64_t conv_wb_index(int tapg, int ci, int co, int p
 }
 
 __global__ void split_conv_planes_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, int tapgroups,
-                                         int cin_pad, int cin_pad16, int cout_pad) {
+                                         int cin_pad, int cin_pad16, int cout_pad, int* __restrict__ ovf) {
   const int64_t total = (int64_t)tapgroups * (cin_pad16 >> 1) * cout_pad;   // one thread per channel PAIR
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int co = (int)(i % cout_pad);
@@ -341,7 +356,7 @@ __global__ void split_conv_planes_kernel(const float* __restrict__ w, bf16_t* __
     const float x1 = ci + 1 < cin_pad ? w[conv_w_index(tg, ci + 1, co, cin_pad, cout_pad)] : 0.f;
     // slot 0: bf16(w) (the autocast mode's operand); slots 1, 2: the fp16 split (hi, scaled lo)
     uint32_t h, l;
-    split2_f16_pk(x0, x1, h, l);
+    split2_f16_pk(x0, x1, h, l, ovf);
     *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 0, cin_pad16, cout_pad)) = cvt_pk_bf16_f32(x0, x1);
     *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 1, cin_pad16, cout_pad)) = h;
     *reinterpret_cast<uint32_t*>(wb + conv_wb_index(tg, ci, co, 2, cin_pad16, cout_pad)) = l;
@@ -352,7 +367,7 @@ int launch_split_conv_planes(const float* w_packed, bf16_t* wb, int tapgroups, i
                              hipStream_t s) {
   FMI_REQUIRE(cin_pad16 % 16 == 0 && cin_pad16 >= cin_pad && cout_pad % 32 == 0, "split planes: bad padding");
   hipLaunchKernelGGL(split_conv_planes_kernel, dim3(2048), dim3(256), 0, s, w_packed, wb, tapgroups, cin_pad, cin_pad16,
-                     cout_pad);
+                     cout_pad, f16_overflow_target());
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
           for (int e = 0; e < 4; ++e) {
             if (NP == 2) {
               uint32_t hh, ll;
-              split2_f16_pk(v[u][2 * e], v[u][2 * e + 1], hh, ll);
+              split2_f16_pk(v[u][2 * e], v[u][2 * e + 1], hh, ll, a.ovf);
               ph[e] = hh; pl[e] = ll;
             } else {
               ph[e] = cvt_pk_bf16_f32(v[u][2 * e], v[u][2 * e + 1]);
@@ -586,8 +601,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
     }
     uint32_t h0, l0 = 0, h1, l1 = 0;
     if (NP == 2) {
-      split2_f16_pk(t[0], t[1], h0, l0);
-      split2_f16_pk(t[2], t[3], h1, l1);
+      split2_f16_pk(t[0], t[1], h0, l0, a.ovf);
+      split2_f16_pk(t[2], t[3], h1, l1, a.ovf);
     } else {
       h0 = cvt_pk_bf16_f32(t[0], t[1]);
       h1 = cvt_pk_bf16_f32(t[2], t[3]);
@@ -914,9 +929,9 @@ int launch_linear_planes(const ConvW& w, const bf16_t* xp, float* out, const flo
 }
 
 // one value as its two fp16 operand-plane halves
-__device__ inline void split1_f16(float x, uint16_t& h, uint16_t& l) {
+__device__ inline void split1_f16(float x, uint16_t& h, uint16_t& l, int* __restrict__ ovf) {
   uint32_t hh, ll;
-  split2_f16_pk(x, 0.f, hh, ll);
+  split2_f16_pk(x, 0.f, hh, ll, ovf);
   h = (uint16_t)hh;
   l = (uint16_t)ll;
 }
@@ -938,7 +953,9 @@ static int launch_conv_t(const ConvArgs& a, int ncols, int tap_off0, int span, h
   return FMI_OK;
 }
 
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+int launch_conv(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  if (!a.ovf) a.ovf = f16_overflow_target();
   const ConvW& w = a.w;
   FMI_REQUIRE(w.w && w.cin_pad % 8 == 0 && w.cout_pad % 32 == 0, "conv: weights not packed");
   const int ncols = (a.out_stride == 1) ? a.lout : a.lout / a.out_stride;
@@ -1012,7 +1029,7 @@ int launch_rmsnorm_cols(const float* x, const float* w, float eps, float* out, i
 // the same statistics; the normalised tensor leaves as fp16 hi/lo operand planes [B][C/16][2][L][16] (C % 16 == 0):
 // a thread writes four channels (8 bytes) of a column per plane
 __global__ __launch_bounds__(32 * NORM_NG) void rmsnorm_cols_planes_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                           float eps, bf16_t* __restrict__ outp, int C, int L) {
+                                                                           float eps, bf16_t* __restrict__ outp, int C, int L, int* __restrict__ ovf) {
   __shared__ float part[NORM_NG][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t = blockIdx.x * 32 + tx, b = blockIdx.y;
@@ -1039,8 +1056,8 @@ __global__ __launch_bounds__(32 * NORM_NG) void rmsnorm_cols_planes_kernel(const
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = xb[(int64_t)(c + e) * L + t] * rstd * w[c + e];
     uint32_t h0, l0, h1, l1;
-    split2_f16_pk(v[0], v[1], h0, l0);
-    split2_f16_pk(v[2], v[3], h1, l1);
+    split2_f16_pk(v[0], v[1], h0, l0, ovf);
+    split2_f16_pk(v[2], v[3], h1, l1, ovf);
     char* dst = ob + (((int64_t)(c >> 4) * 2) * L + t) * 32 + (c & 15) * 2;
     *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(dst + (int64_t)L * 32) = make_uint2(l0, l1);
@@ -1049,7 +1066,7 @@ __global__ __launch_bounds__(32 * NORM_NG) void rmsnorm_cols_planes_kernel(const
 
 int launch_rmsnorm_cols_planes(const float* x, const float* w, float eps, bf16_t* outp, int B, int C, int L, hipStream_t s) {
   FMI_REQUIRE(C % 16 == 0, "rmsnorm planes: C %% 16");
-  hipLaunchKernelGGL(rmsnorm_cols_planes_kernel, dim3(cdiv(L, 32), B), dim3(32 * NORM_NG), 0, s, x, w, eps, outp, C, L);
+  hipLaunchKernelGGL(rmsnorm_cols_planes_kernel, dim3(cdiv(L, 32), B), dim3(32 * NORM_NG), 0, s, x, w, eps, outp, C, L, f16_overflow_target());
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -1131,7 +1148,7 @@ __global__ void silu_mul_kernel(const float* __restrict__ ab, float* __restrict_
 }
 
 // SiLU(gate) * up as operand planes [B][F/16][2][L][16]: thread = (column, channel quad)
-__global__ __launch_bounds__(256) void silu_mul_planes_kernel(const float* __restrict__ ab, bf16_t* __restrict__ outp, int F, int L) {
+__global__ __launch_bounds__(256) void silu_mul_planes_kernel(const float* __restrict__ ab, bf16_t* __restrict__ outp, int F, int L, int* __restrict__ ovf) {
   const int t = blockIdx.x * 64 + (threadIdx.x & 63), f = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4, b = blockIdx.z;
   if (t >= L || f >= F) return;
   float v[4];
@@ -1142,8 +1159,8 @@ __global__ __launch_bounds__(256) void silu_mul_planes_kernel(const float* __res
     v[e] = (g / (1.0f + expf(-g))) * u;
   }
   uint32_t h0, l0, h1, l1;
-  split2_f16_pk(v[0], v[1], h0, l0);
-  split2_f16_pk(v[2], v[3], h1, l1);
+  split2_f16_pk(v[0], v[1], h0, l0, ovf);
+  split2_f16_pk(v[2], v[3], h1, l1, ovf);
   char* dst = reinterpret_cast<char*>(outp) + ((((int64_t)b * (F >> 4) + (f >> 4)) * 2) * L + t) * 32 + (f & 15) * 2;
   *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(dst + (int64_t)L * 32) = make_uint2(l0, l1);
@@ -1151,7 +1168,7 @@ __global__ __launch_bounds__(256) void silu_mul_planes_kernel(const float* __res
 
 int launch_silu_mul_planes(const float* ab, bf16_t* outp, int B, int F, int L, hipStream_t s) {
   FMI_REQUIRE(F % 16 == 0, "silu_mul planes: F %% 16");
-  hipLaunchKernelGGL(silu_mul_planes_kernel, dim3(cdiv(L, 64), F / 16, B), dim3(256), 0, s, ab, outp, F, L);
+  hipLaunchKernelGGL(silu_mul_planes_kernel, dim3(cdiv(L, 64), F / 16, B), dim3(256), 0, s, ab, outp, F, L, f16_overflow_target());
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
@@ -1257,7 +1274,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 template <int QT>
 __global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                               int C, int L, int window, int ld, int q_lo,
-                                                              bf16_t* __restrict__ outp) {
+                                                              bf16_t* __restrict__ outp, int* __restrict__ ovf) {
   constexpr int HD = 64;
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   const int KT = QT + window - 1, RS = KT | 1;
@@ -1318,7 +1335,7 @@ __global__ __launch_bounds__(256) void window_attn_lds_kernel(const float* __res
     if (outp) {   // fp16 hi/lo operand planes [B][C/16][2][L - q_lo][16] for linear_planes_kernel
       const int c = h * HD + lane, n = L - q_lo;
       uint16_t hh, ll;
-      split1_f16(o / den, hh, ll);
+      split1_f16(o / den, hh, ll, ovf);
       char* dst = reinterpret_cast<char*>(outp) + ((((int64_t)b * (C >> 4) + (c >> 4)) * 2) * n + (t - q_lo)) * 32 + (c & 15) * 2;
       *reinterpret_cast<uint16_t*>(dst) = hh;
       *reinterpret_cast<uint16_t*>(dst + (int64_t)n * 32) = ll;
@@ -1342,7 +1359,7 @@ int launch_window_attn(const float* qkv, float* out, int B, int C, int L, int hd
       FMI_CHECK_HIP(hipFuncSetAttribute((const void*)window_attn_lds_kernel<QT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)smem));
     hipLaunchKernelGGL((window_attn_lds_kernel<QT>), dim3(cdiv(nq, QT), C / hd, B), dim3(256), smem, s, qkv, out, C, L,
-                       window, ld, q_lo, outp);
+                       window, ld, q_lo, outp, f16_overflow_target());
     FMI_CHECK_HIP(hipGetLastError());
     return FMI_OK;
   }
@@ -1570,14 +1587,11 @@ int launch_final_conv_tanh(const float* x, const float* alpha, const float* w, c
   return FMI_OK;
 }
 
-int read_clear_f16_overflow(int* flag, hipStream_t s) {
+int read_clear_f16_overflow(int* dev_word, int* flag, hipStream_t s) {
   int v = 0;
   FMI_CHECK_HIP(hipStreamSynchronize(s));
-  FMI_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_overflow), sizeof(int)));
-  if (v) {
-    const int zero = 0;
-    FMI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_f16_overflow), &zero, sizeof(int)));
-  }
+  FMI_CHECK_HIP(hipMemcpy(&v, dev_word, sizeof(int), hipMemcpyDeviceToHost));
+  if (v) FMI_CHECK_HIP(hipMemset(dev_word, 0, sizeof(int)));
   *flag = v;
   return FMI_OK;
 }

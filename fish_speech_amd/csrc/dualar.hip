@@ -1302,6 +1302,16 @@ int fmi_dualar_table_ptr(fmi_dualar* h, int which, void** ptr, int* rows, int* c
   return FMI_OK;
 }
 
+// What this handle has derived from the arena so far (row-balanced decode copies, the fast layer-0 q|k|v table): both are
+// built lazily by the first prefill on EVERY rank -- they are not part of the broadcast.
+int fmi_dualar_derived_info(fmi_dualar* h, int* row_copies, int* table_rows, int* loaded_tensors) {
+  FMI_REQUIRE(h, "null handle");
+  if (row_copies) *row_copies = (int)h->row_copies.size();
+  if (table_rows) *table_rows = h->qkv0_tab ? h->cfg.codebook_size : 0;
+  if (loaded_tensors) *loaded_tensors = (int)h->loaded.size();
+  return FMI_OK;
+}
+
 int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* ld_logits, void** live_ids,
                           void** hidden, void** fast_logits) {
   FMI_REQUIRE(h, "null handle");
@@ -1316,6 +1326,10 @@ int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* l
 
 int fmi_dualar_set_trace(fmi_dualar* h, int enable, void** fast_trace) {
   FMI_REQUIRE(h, "null handle");
+  if (h->trace != (enable != 0)) {   // the captured frames embed (or lack) the trace copies and the table's use
+    FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+  }
   h->trace = enable != 0;
   if (fast_trace) *fast_trace = h->ftrace;
   return FMI_OK;
@@ -1335,6 +1349,22 @@ int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl) {
   FMI_REQUIRE(h, "null handle");
   FMI_REQUIRE(impl == 0 || impl == 1, "attn impl must be 0 (VALU) or 1 (MFMA)");
   h->attn_impl = impl;
+  return FMI_OK;
+}
+
+// The handle's private stream re-created with a dispatch priority (-1 = highest, 0 = default, 1 = lowest): when another
+// queue (the codec of the previous batch) is busy beside the frame loop, the loop's launches go first.
+int fmi_dualar_set_stream_priority(fmi_dualar* h, int priority) {
+  FMI_REQUIRE(h, "null handle");
+  FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
+  drop_graphs(h);
+  int lo = 0, hi = 0;
+  FMI_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  const int pr = priority < 0 ? hi : (priority > 0 ? lo : (lo + hi) / 2);
+  hipStream_t ns = nullptr;
+  FMI_CHECK_HIP(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, pr));
+  hipStreamDestroy(h->stream);
+  h->stream = ns;
   return FMI_OK;
 }
 

@@ -567,6 +567,41 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
         xh[s][u] = *reinterpret_cast<const uint4*>(&nf);
       }
     }
+  } else if (NORM && (a.K & 63) == 0 && (a.K >> 6) == SKINNY_XH * WAVES) {
+    // A shape the held-fragment variants (XH > 0) also serve, e.g. the 9-16-row SwiGLU form next to the <= 8-row one:
+    // the statistics take THEIR partition and reduction tree -- wave w over its own k-slice, lane (chunk, row)
+    // sequentially over its pairs and elements, xor tree over the eight chunk lanes, waves summed in order -- so that a
+    // row's rstd, hence every bit of its result, does not depend on which variant the row count of the call selects
+    // (row_rstd's lane-strided sum + wave_sum is another fp32 order).  The fragments are not held: they are
+    // re-read (L2 hits) by the product loop below.
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      uint4 xt[SKINNY_XH];
+#pragma unroll
+      for (int u = 0; u < SKINNY_XH; ++u) xt[u] = *xptr(s, pbeg + u);
+      float ss = 0.f;
+#pragma unroll
+      for (int u = 0; u < SKINNY_XH; ++u) {
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&xt[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = bf2f(e[j]);
+          ss = fmaf(f, f, ss);
+        }
+      }
+      ss += __shfl_xor(ss, 8, 64);
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lane < 8) s_part[wave][s * 8 + lane] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tot += s_part[w][s * 8 + (lane & 7)];
+      rstd[s] = rsqrtf(tot / (float)a.K + a.eps);
+    }
   } else if (NORM) {
     for (int r = wave; r < a.M; r += WAVES) {
       float v = row_rstd(a.x + (int64_t)r * a.ldx, a.K, a.eps, lane);

@@ -247,6 +247,8 @@ class MiDAC:
         self._dtype_probe = torch.empty(0, dtype=torch.float32, device=self.device)
         self._planes = 2                       # decode-side arithmetic outside autocast (set_precision)
         self._lock = threading.RLock()         # (precision, call) pairs of concurrent request threads stay together
+        self._async = False
+        self._fp32_streams: set = set()        # open streams that fell back to the fp32 matrix cores (_decode_call)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -315,6 +317,32 @@ class MiDAC:
     def weights_ready(self):
         check(self.lib.fmi_dac_weights_ready(self._h))
 
+    # ---- running beside the Dual-AR frame loop (fishmi.h: fmi_dac_set_async / fmi_dac_set_stream_options)
+    def set_async(self, enable: bool):
+        """encode / decode calls return once enqueued on the codec's own stream and no longer make torch's current stream
+        wait; order a consumer with `wait_stream()` or wait with `synchronize()` before reading the result."""
+        check(self.lib.fmi_dac_set_async(self._h, int(bool(enable))))
+        self._async = bool(enable)
+        return self
+
+    def wait_stream(self):
+        """order torch's current stream after the codec calls enqueued so far (no host wait)"""
+        check(self.lib.fmi_dac_wait(self._h, self._stream()))
+
+    def synchronize(self):
+        """host wait for everything enqueued on the codec's stream"""
+        check(self.lib.fmi_dac_synchronize(self._h))
+
+    def set_stream_options(self, priority: int = 0, cu_mask: Optional[Sequence[int]] = None):
+        """priority: -1 highest, 0 default, 1 lowest; cu_mask: 32-bit words, bit i = compute unit i may run this codec's
+        kernels (overrides the priority)."""
+        if cu_mask:
+            words = (C.c_uint32 * len(cu_mask))(*[int(w) & 0xFFFFFFFF for w in cu_mask])
+            check(self.lib.fmi_dac_set_stream_options(self._h, int(priority), len(cu_mask), words))
+        else:
+            check(self.lib.fmi_dac_set_stream_options(self._h, int(priority), 0, None))
+        return self
+
     def set_precision(self, planes: int):
         """Decode-side contraction arithmetic: 2 = fp16 matrix cores on the scaled two-term operand split (fp32-class,
         the default), 0 = fp32 matrix cores (round-1 path), 1 = bf16 operands and results (what autocast selects);
@@ -324,14 +352,19 @@ class MiDAC:
             self._planes = int(planes)
         return self
 
-    def _decode_call(self, fn, *args):
+    def _decode_call(self, fn, *args, stream_id: Optional[int] = None):
         """Run one decode-side entry point with the arithmetic the caller's context asks for: inside
         ``torch.autocast(device_type="cuda", dtype=torch.bfloat16)`` -- how the engine calls from_indices
         (fish_speech/inference_engine/__init__.py:179-192) -- every conv / linear rounds its operands and its result to
         bf16 with fp32 accumulation, as autocast does to F.conv1d / F.conv_transpose1d / F.linear; elementwise ops,
         norms and residual adds stay fp32 (torch's type promotion gives fp32 there too, parameters being fp32).
-        Outside autocast the configured precision applies (default: the fp32-class fp16-split arithmetic)."""
+        Outside autocast the configured precision applies (default: the fp32-class fp16-split arithmetic).
+        `stream_id`: a stream that once needed the fp32 fallback (check_overflow) stays on the fp32 matrix cores until it is
+        closed -- its kept quantizer-side state was rebuilt in that arithmetic, and chunks that alternate between the two
+        would neither be bit-identical to an offline decode nor cheap (every overflowing chunk recomputes the stream)."""
         planes = self._planes
+        if planes == 2 and stream_id is not None and stream_id in self._fp32_streams:
+            planes = 0
         if self.module_dtype == torch.bfloat16:
             planes = 1
         elif torch.is_autocast_enabled("cuda"):
@@ -343,11 +376,13 @@ class MiDAC:
             check(self.lib.fmi_dac_set_precision(self._h, planes))
             try:
                 check(fn(self._h, *args))
-                if planes == 2 and self.check_overflow and self.fp16_overflowed():
+                if planes == 2 and self.check_overflow and not self._async and self.fp16_overflowed():
                     # saturated samples, not NaNs -- but not the reference's either: redo on the fp32 matrix cores
                     self.overflow_fallbacks += 1
                     check(self.lib.fmi_dac_set_precision(self._h, 0))
                     planes = 0
+                    if stream_id is not None:
+                        self._fp32_streams.add(stream_id)
                     check(fn(self._h, *args))
             finally:
                 if planes != self._planes:
@@ -479,7 +514,8 @@ class MiDAC:
                               C.c_void_p(out.data_ptr()), self._stream())
         else:
             self._decode_call(self.lib.fmi_dac_decode_tail_cached, C.c_void_p(work.data_ptr()), B, T, int(t0),
-                              C.c_int64(int(stream_id)), C.c_void_p(out.data_ptr()), self._stream())
+                              C.c_int64(int(stream_id)), C.c_void_p(out.data_ptr()), self._stream(),
+                              stream_id=int(stream_id))
         self._keep = work
         return out
 
@@ -492,11 +528,13 @@ class MiDAC:
     def stream_reset(self) -> None:
         """free the device state kept for from_indices_tail(stream_id=...)"""
         check(self.lib.fmi_dac_stream_reset(self._h))
+        self._fp32_streams.clear()
 
     def close_stream(self, stream_id: int) -> None:
         """The stream `stream_id` has ended: drop its incremental state now (fmi_dac_stream_close) instead of letting it
         age out of the 16 kept states."""
         check(self.lib.fmi_dac_stream_close(self._h, int(stream_id)))
+        self._fp32_streams.discard(int(stream_id))
 
     @property
     def context_frames(self) -> int:

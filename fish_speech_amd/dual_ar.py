@@ -534,12 +534,23 @@ class MiDualAR:
         check(self.lib.fmi_dualar_last_decode_stats(self._h, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
 
+    def derived_info(self) -> Dict[str, int]:
+        """What this handle derived from its arena locally (dist.py: not part of the broadcast) and how many tensors it
+        was given through load_state_dict (0 on a rank fed by the broadcast + weights_ready alone)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.fmi_dualar_derived_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"row_copies": a.value, "table_rows": b.value, "loaded_tensors": c.value}
+
     def set_graph(self, enable: bool):
         check(self.lib.fmi_dualar_set_graph(self._h, int(enable)))
 
     def set_attn_impl(self, impl: int):
         """Prefill attention kernel: 1 = MFMA flash attention (default), 0 = VALU kernel (A/B parity runs)."""
         check(self.lib.fmi_dualar_set_attn_impl(self._h, int(impl)))
+
+    def set_stream_priority(self, priority: int):
+        """Dispatch priority of the model's private stream: -1 highest, 0 default, 1 lowest (re-creates the stream)."""
+        check(self.lib.fmi_dualar_set_stream_priority(self._h, int(priority)))
 
     def set_fast_merge(self, enable: bool):
         """Fast positions 0 and 1 of a frame in one pass over the fast weights (default) or in two (A/B parity runs)."""
@@ -728,11 +739,13 @@ def generate_batch(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_
 @torch.no_grad()
 def generate_batch_device(*, model: MiDualAR, prompts: Sequence[torch.Tensor], max_new_tokens: int,
                           seeds: Optional[Sequence[int]] = None, temperature: float = 1.0, top_p: float = 0.9,
-                          top_k: int = 30, use_ras: bool = True) -> torch.Tensor:
+                          top_k: int = 30, use_ras: bool = True, wait: bool = True):
     """Fixed-length batch generation whose result stays on the device: returns the codebook rows
     (B, num_codebooks, max_new_tokens) int64, ready for ``MiDAC.from_indices`` -- no host round trip
     between the Dual-AR loop and the codec.  Every slot runs exactly ``max_new_tokens`` frames
-    (use ``model.set_ignore_eos(True)``), so this is the serving/benchmark path for known lengths."""
+    (use ``model.set_ignore_eos(True)``), so this is the serving/benchmark path for known lengths.
+    ``wait=False``: returns as soon as the prefill and the frames are ENQUEUED on the model's stream (no host wait);
+    pass the returned token to :func:`finish_batch_device` for the codes."""
     cfg = model.config
     n = len(prompts)
     if not model._cache_setup_done:
@@ -751,8 +764,19 @@ def generate_batch_device(*, model: MiDualAR, prompts: Sequence[torch.Tensor], m
     model.prefill(slots, prompts, [max_new_tokens] * n, samp)
     if max_new_tokens > 1:
         model.decode(slots, max_new_tokens - 1)
+    if not wait:
+        return (n, max_new_tokens)
+    return finish_batch_device(model, (n, max_new_tokens))
+
+
+def finish_batch_device(model: MiDualAR, pending) -> torch.Tensor:
+    """Second half of ``generate_batch_device(..., wait=False)``: waits for the frames (host), copies the codebook rows
+    out of the library's buffer and releases the slots.  Between the two halves the host is free -- bench.py and
+    serving enqueue the PREVIOUS batch's codec decode there, so that the MFMA-bound codec runs beside the HBM-bound
+    frame loop instead of after it."""
+    n, max_new_tokens = pending
     out = model.frames_device(n, max_new_tokens)          # (B, frames, 1+ncb) int32 view
     codes = out[:, :, 1:].permute(0, 2, 1).to(torch.int64).contiguous()
-    for i in slots:
+    for i in range(n):
         model.release(i)
     return codes

@@ -2,11 +2,14 @@
 -- references by id from `references/<id>/` or by content hash, with the two in-memory caches) and `VQManager`
 (fish_speech/inference_engine/vq_manager.py:16-53 -- `encode_reference`, `decode_vq_tokens`) over a `MiDAC`.
 
-Same method names, arguments, cache keys, validation and error types as upstream; what differs is audio I/O:
+The DATA-PATH methods (`load_by_id`, `load_by_hash`, `load_audio`, `encode_reference`, `decode_vq_tokens`) keep upstream's
+names, arguments, cache keys, validation and error types; NOT mirrored -- a stated gap, see INTEGRATION.md "What is not
+mirrored" -- are the three reference-library management methods upstream's class also defines
+(`list_reference_ids`, `add_reference`, `delete_reference`, reference_loader.py:155-260: directory listing / copy /
+delete behind the HTTP server's routes, control plane per SURVEY.md 8).  What else differs is audio I/O:
 torchaudio is not in this image, so `load_audio` reads wav bytes / files with scipy and resamples with a polyphase
 filter (host plumbing outside the hot path; mp3 / flac / ... references raise a clear error instead of being
-mis-decoded).  `engine.StreamingTTSEngine` inherits both, like `TTSInferenceEngine` does.  The reference-management
-routes of the HTTP server (`add_reference` / `delete_reference` / `list_reference_ids`) are control plane and are not mirrored."""
+mis-decoded).  `engine.StreamingTTSEngine` inherits both, like `TTSInferenceEngine` does."""
 from __future__ import annotations
 
 import io

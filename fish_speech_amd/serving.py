@@ -171,9 +171,11 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
                 # caller's bug); from a feed it fails alone -- an "error" event for its owner, the loop and everybody
                 # else's utterances go on (one bad request used to end the loop for all of them)
                 try:
-                    T = r.prompt.size(1)
+                    if not torch.is_tensor(r.prompt):
+                        raise TypeError(f"prompt must be an integer tensor ({cfg.num_codebooks + 1}, T), got {type(r.prompt).__name__}")
                     if r.prompt.dim() != 2 or r.prompt.size(0) != cfg.num_codebooks + 1:
                         raise ValueError(f"prompt must be ({cfg.num_codebooks + 1}, T), got {tuple(r.prompt.shape)}")
+                    T = r.prompt.size(1)
                     if T >= cfg.max_seq_len:  # inference.py:263-266
                         raise ValueError(f"Input sequence length {T} exceeds max_seq_len {cfg.max_seq_len}")
                     limit = min(r.max_new_tokens if r.max_new_tokens else cfg.max_seq_len - T, cfg.max_seq_len - T)
@@ -181,7 +183,7 @@ def serve_stream(*, model, codec, requests: Iterable[StreamRequest], max_batch: 
                                            opt(r.chunk_growth, chunk_growth), opt(r.max_chunk_frames, max_chunk_frames))
                     sp = model._sampling(opt(r.temperature, temperature), opt(r.top_p, top_p), opt(r.top_k, top_k),
                                          r.seed if r.seed is not None else model.next_seed(), use_ras)
-                except (ValueError, TypeError) as e:
+                except Exception as e:   # noqa: BLE001 -- whatever a malformed request trips, it fails ALONE
                     if feed is None:
                         raise
                     yield StreamEvent(r.rid, "error", 0, 0, None, None, clock() - start, error=str(e))

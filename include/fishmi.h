@@ -160,6 +160,13 @@ int fmi_dualar_forward_fast(fmi_dualar* h, int slot, const void* hidden_in_dev, 
  * (codebook_size x fast_dim bf16), 1 = vocab id of each live logits row (int32 [n_live]). */
 int fmi_dualar_table_ptr(fmi_dualar* h, int which, void** ptr, int* rows, int* cols);
 
+/* What the handle derived from the arena content on THIS process (ranks > 0 receive the arena by
+ * broadcast and never see load_tensor / finalize): the number of row-balanced decode copies, the rows of the fast
+ * layer-0 q|k|v table (0 = not built), and how many tensors went through fmi_dualar_load_tensor* on this handle
+ * (0 on a rank that was fed by fmi_dualar_weights_ready alone).  Replaces nothing upstream: the reference loads the
+ * checkpoint on every rank (tools/vqgan/extract_vq.py:161-207). */
+int fmi_dualar_derived_info(fmi_dualar* h, int* row_copies, int* table_rows, int* loaded_tensors);
+
 /* Debug / parity taps (device pointers owned by the library, valid until the next call):
  * live-row logits of the last slow step (bf16, [B][n_live_padded]), the vocab id of each
  * live row (int32 [n_live]), the hidden rows handed to the fast transformer (bf16 [B][fast_dim]: the normed hidden,
@@ -182,6 +189,11 @@ int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl);
  * (default when 2 x batch <= 16, bf16 weights, fast_dim == dim), 0 = two passes (rounds 1-3; kept for A/B parity runs).
  * Results are bit-identical either way. */
 int fmi_dualar_set_fast_merge(fmi_dualar* h, int enable);
+/* Dispatch priority of the handle's private stream (-1 highest, 0 default, 1 lowest); the stream is re-created, graphs
+ * are re-captured.  For a frame loop that shares the GPU with another queue (the codec decode of the previous batch:
+ * fmi_dac_set_async / fmi_dac_set_stream_options).  The reference has one CUDA stream and nothing to overlap
+ * (fish_speech/inference_engine/__init__.py:73-140 decodes a segment between two generate calls). */
+int fmi_dualar_set_stream_priority(fmi_dualar* h, int priority);
 /* Decode attention (the per-frame step of llama.py:910-934 over the KV cache): rows whose position is >= threshold run
  * on the MFMA kernel (all query heads of a kv head in one work-group, key ranges split over work-groups, partial
  * softmax states merged), the others on the fused VALU kernel; which one depends only on the row's own position.
@@ -270,6 +282,20 @@ int fmi_dac_set_precision(fmi_dac* h, int planes);
  * caller that sees 1 repeats the decode with fmi_dac_set_precision(h, 0).  fish_speech_amd.dac.MiDAC does so when
  * constructed with check_overflow=True. */
 int fmi_dac_fp16_overflow(fmi_dac* h, int* overflowed);
+
+/* Running a codec call BESIDE the Dual-AR frame loop (the MFMA-bound codec and the HBM-bound loop use different parts
+ * of the chip; upstream decodes between generate calls, fish_speech/inference_engine/__init__.py:73-140,179-192):
+ *   fmi_dac_set_async(h, 1): encode / decode entry points return once their kernels are enqueued on the handle's own
+ *     stream and do NOT make the caller's `stream` wait (a cross-queue wait pending for the length of the call taxes
+ *     every dispatch of the other queue); the caller orders a consumer with fmi_dac_wait(h, stream) or waits with
+ *     fmi_dac_synchronize(h), and keeps the input / output buffers alive until then.
+ *   fmi_dac_set_stream_options: re-creates the handle's stream with a dispatch priority (-1 highest, 0 default,
+ *     1 lowest) or, when cu_mask_words > 0, with a CU mask (bit i = compute unit i may run this handle's kernels;
+ *     hipExtStreamCreateWithCUMask) -- the codec can be confined to part of the chip while the loop keeps the rest. */
+int fmi_dac_set_async(fmi_dac* h, int enable);
+int fmi_dac_wait(fmi_dac* h, void* stream);
+int fmi_dac_synchronize(fmi_dac* h);
+int fmi_dac_set_stream_options(fmi_dac* h, int priority, int cu_mask_words, const uint32_t* cu_mask);
 
 /* DAC.from_indices (fish_speech/models/dac/modded_dac.py:925-927): indices int64
  * (B,1+n_codebooks,T) -> audio fp32 (B,1,T*frame_length).  Like the reference

@@ -68,7 +68,8 @@ def bf16_close(a: torch.Tensor, b: torch.Tensor, ulps: float = 2.0, scale=None, 
 # --------------------------------------------------------------------------------------------------
 
 
-def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float = 8.0, rel_l2: float = 2e-2):
+def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float = 8.0, rel_l2: float = 2e-2,
+                         decide: str = "near_argmax"):
     """step_fn(frame, x (S,1+ncb) int tensor, pos0, prev_window or None) ->
            (tokens (1+ncb,), slow_logits_live (n_live,), hidden (dim,), fast_logits (ncb-1, cbs))
 
@@ -83,6 +84,9 @@ def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float
         margin exceeds the rounding noise of a different fp32 summation order, and never an outlier;
       * exact equality with the reference token when that token came from the u == 0 quirk of the
         exponential race (inference.py:43-46), which does not depend on the logits.
+    decide="equal" (SAMPLED fixtures: the step function draws with the fixture's top-k / top-p / temperature / seed, and
+    the fixture's draws are invariant under two bf16 steps of logit noise): every decision must EQUAL the reference's
+    token -- the taps are checked the same way.
     Returns statistics for reporting."""
     from oracle import dual_ar as O
 
@@ -129,7 +133,9 @@ def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float
         assert e <= ulps, f"frame {f}: hidden {e:.2f} ulps off the reference"
         # slow decision
         ref_tok = int(want[0])
-        if ref_tok == 0 and 0 not in ids.tolist():  # u == 0 quirk: independent of the logits
+        if decide == "equal":
+            assert int(tok[0]) == ref_tok, f"frame {f}: slow token {int(tok[0])} != the reference's {ref_tok}"
+        elif ref_tok == 0 and 0 not in ids.tolist():  # u == 0 quirk: independent of the logits
             assert int(tok[0]) == 0, f"frame {f}: the u==0 draw must return token 0"
         else:
             picked = (ids == int(tok[0])).nonzero()
@@ -149,7 +155,9 @@ def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float
             got_c, ref_c = int(tok[1 + cb]), int(want[1 + cb])
             ref_is_argmax = int(ref_fast[f, cb - 1].float().argmax()) == ref_c or \
                 float(ref_fast[f, cb - 1].float()[ref_c]) == float(ref_fast[f, cb - 1].float().max())
-            if not ref_is_argmax and ref_c == 0:  # u == 0 quirk
+            if decide == "equal":
+                assert got_c == ref_c, f"frame {f} cb {cb}: code {got_c} != the reference's {ref_c}"
+            elif not ref_is_argmax and ref_c == 0:  # u == 0 quirk
                 assert got_c == 0, f"frame {f} cb {cb}: the u==0 draw must return code 0"
             else:
                 assert near_argmax(ref_fast[f, cb - 1], got_c, ref_c), \
@@ -164,15 +172,17 @@ def check_teacher_forced(step_fn, cfg, z, ulps: float = 16.0, decide_ulps: float
     return stats
 
 
-def oracle_step_fn(cfg, state, uniform_seed):
-    """The CPU oracle behind the check_teacher_forced protocol."""
+def oracle_step_fn(cfg, state, uniform_seed, temperature: float = 0.7, top_p: float = 0.7, top_k: int = 1, hook=None):
+    """The CPU oracle behind the check_teacher_forced protocol.  `hook(orc)`: tests/mutations.py injects faults."""
     from oracle import dual_ar as O
 
     orc = O.DualAROracle(cfg, state)
     orc.setup_caches(1, cfg.max_seq_len)
-    ids = None
+    if hook is not None:
+        hook(orc)
     bias = O.semantic_logit_bias(cfg, orc.dtype)
-    temp = torch.tensor(0.7, dtype=orc.dtype)
+    temp = torch.tensor(temperature, dtype=orc.dtype)
+    tp = torch.tensor(top_p, dtype=orc.dtype)
     u = O.FmiUniform(uniform_seed, 0)
     ncb1 = cfg.num_codebooks + 1
 
@@ -182,7 +192,7 @@ def oracle_step_fn(cfg, state, uniform_seed):
         S = x.shape[0]
         xt = x.t().contiguous().view(1, ncb1, S).long()
         pos = torch.arange(pos0, pos0 + S)
-        out = O.decode_one_token(orc, xt, pos, temp, temp, 1, bias, prev, u, math_backend=(f > 0))
+        out = O.decode_one_token(orc, xt, pos, temp, tp, top_k, bias, prev, u, math_backend=(f > 0))
         live = torch.tensor(sorted(set(range(cfg.semantic_begin_id, cfg.semantic_end_id + 1)) | {cfg.im_end_id}))
         return (out.view(-1), orc.trace["slow_logits"][0][live], orc.trace["hidden"][0],
                 torch.stack(orc.trace["fast_logits"][0]))

@@ -384,6 +384,48 @@ def test_fp16_split_saturates_and_flags_instead_of_producing_nans(small):
     assert safe.overflow_fallbacks == 1 and rms(got, want) <= 1e-4 * max(1.0, float(want.abs().max()))
 
 
+def test_fp16_overflow_flag_belongs_to_the_handle_that_overflowed(small):
+    """ADVICE r03 / VERDICT r04 #7: the flag was one process-wide device word, so a second codec (or a request thread on
+    it) could consume another handle's overflow and return saturated audio without the fp32 retry.  Two MiDAC
+    instances, one with weights far outside the fp16 range: only ITS flag rises, in whatever order the two are used and
+    read; a stream that fell back once stays on the fp32 matrix cores until it is closed."""
+    from fish_speech_amd.dac import DacConfig, MiDAC
+
+    cfg, state, z, quiet = small
+    big = {k: v.clone() for k, v in state.items()}
+    k0 = "decoder.model.0.conv.parametrizations.weight.original0"
+    big[k0] = big[k0] * 3.0e5
+    loud = MiDAC.from_state_dict(DacConfig.from_any(cfg), big, device=DEV)
+    loud.fp16_overflowed()
+    quiet.fp16_overflowed()
+    codes = D.make_codes(cfg, 1, 6, seed=11)
+    want_quiet = quiet.from_indices(codes.clone().to(DEV)).cpu()
+    assert not quiet.fp16_overflowed()
+    # loud overflows; reading QUIET's flag first must neither see nor consume it
+    out = loud.from_indices(codes.clone().to(DEV))
+    assert bool(torch.isfinite(out).all())
+    got_quiet = quiet.from_indices(codes.clone().to(DEV)).cpu()
+    assert not quiet.fp16_overflowed() and torch.equal(got_quiet, want_quiet)
+    assert loud.fp16_overflowed() and not loud.fp16_overflowed()
+    # interleaved the other way round: quiet decodes between loud's decode and loud's read
+    loud.from_indices(codes.clone().to(DEV))
+    quiet.from_indices(codes.clone().to(DEV))
+    assert loud.fp16_overflowed() and not quiet.fp16_overflowed()
+    # streaming on a checking handle: the first chunk falls back, later chunks of that stream go straight to fp32
+    safe = MiDAC(DacConfig.from_any(cfg), device=DEV, check_overflow=True).load_state_dict(big)
+    safe.fp16_overflowed()
+    sid = MiDAC.new_stream_id()
+    want = D.DacOracle(cfg, big).from_indices(codes.clone())
+    a = safe.from_indices_tail(codes[:, :, :3].clone().to(DEV), 0, stream_id=sid)
+    assert safe.overflow_fallbacks == 1 and sid in safe._fp32_streams
+    b = safe.from_indices_tail(codes.clone().to(DEV), 3, stream_id=sid)
+    assert safe.overflow_fallbacks == 1, "the second chunk must not have tried the fp16 split again"
+    got = torch.cat([a, b], dim=-1)
+    assert rms(got, want) <= 1e-4 * max(1.0, float(want.abs().max()))
+    safe.close_stream(sid)
+    assert sid not in safe._fp32_streams
+
+
 def test_concurrent_from_indices_from_request_threads(small):
     """request threads share the codec object (tools/api_server.py:115-122 -> get_audio_segment).  Four
     threads decode different codes at once, some inside autocast: every result equals the sequential one."""

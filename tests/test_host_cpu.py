@@ -417,12 +417,15 @@ def test_serve_stream_feed_a_bad_request_fails_alone():
     too_long = StreamRequest(prompt=torch.zeros(NCB + 1, 64, dtype=torch.int64), seed=3, rid=2)
     malformed = StreamRequest(prompt=torch.zeros(NCB, 5, dtype=torch.int64), seed=4, rid=3)
     other = StreamRequest(prompt=torch.zeros(NCB + 1, 7, dtype=torch.int64), seed=5, rid=4, max_new_tokens=6)
+    one_dim = StreamRequest(prompt=torch.zeros(5, dtype=torch.int64), seed=6, rid=5)      # .size(1) came first
+    not_a_tensor = StreamRequest(prompt=[[0] * 5] * (NCB + 1), seed=7, rid=6)
     feed = RequestFeed()
-    for r in (good, too_long, malformed, other):
+    for r in (good, too_long, malformed, one_dim, not_a_tensor, other):
         feed.put(r)
     evs = list(serve_stream(model=model, codec=codec, requests=feed, max_batch=2, step_frames=4, return_when_idle=True))
     errs = {e.rid: e.error for e in evs if e.kind == "error"}
-    assert set(errs) == {2, 3} and "exceeds max_seq_len" in errs[2] and "prompt must be" in errs[3]
+    assert set(errs) == {2, 3, 5, 6} and "exceeds max_seq_len" in errs[2] and "prompt must be" in errs[3]
+    assert "prompt must be" in errs[5] and "prompt must be" in errs[6]
     assert sorted(e.rid for e in evs if e.kind == "final") == [1, 4] and not model.slots
     got = collect(evs, codec.frame_length)
     assert torch.equal(got[1][1], model.expected_codes(11, 6)) and torch.equal(got[4][1], model.expected_codes(5, 6))

@@ -39,7 +39,7 @@ def _load(name):
 _models = {}
 
 
-def _model(skw, max_seq_len=512, slots=8):
+def _model(skw, max_seq_len=512, slots=16):
     """One HIP model per weight recipe (greedy cases share theirs), built on the device; kept for the module."""
     from fish_speech_amd.dual_ar import MiDualAR
 
@@ -117,6 +117,82 @@ def test_s2_golden_utterances_inside_a_ragged_batch_of_8():
                          seeds=seeds, stop_on_im_end=False)
     for row in range(8):
         assert np.array_equal(out[row].numpy(), want[row]), f"row {row} (T = {lens[row]}) differs from the reference"
+
+
+def _ragged_prompts():
+    zp, skw = _load("s2_plain")
+    zc, _ = _load("s2_clone")
+    zr, _ = _load("s2_ragged")
+    prompts, seeds = [None] * 8, [None] * 8
+    prompts[2], seeds[2] = torch.from_numpy(zp["prompt"]), int(zp["uniform_seed"])
+    prompts[5], seeds[5] = torch.from_numpy(zc["prompt"]), int(zc["uniform_seed"])
+    for row in zr["rows"].tolist():
+        prompts[row], seeds[row] = torch.from_numpy(zr[f"prompt_{row}"]), int(zr["uniform_seed_base"]) + row
+    return skw, prompts, seeds
+
+
+def _run_with_taps(model, prompts, seeds, frames, trace=True):
+    """prefill + `frames` graph-replayed frames of a batch; -> (token matrices, slow logits, hidden, fast logits of the
+    last frame), the float taps as raw bf16 bit patterns.  trace=True: the logits of every fast position (the trace
+    switches the per-code q|k|v table of fast layer 0 off, so layer 0 runs its GEMV); trace=False: the last position's
+    logits only, with the table in use -- the frame the benchmark runs."""
+    n = len(prompts)
+    slots = list(range(n))
+    samp = [model._sampling(0.7, 0.7, 1, seeds[i], True) for i in range(n)]
+    model.set_trace(trace)
+    model.set_graph(not trace)        # (the traced frames run eagerly; graph == eager is asserted by the sequence tests)
+    model.prefill(slots, prompts, [frames + 1] * n, samp)
+    model.decode(slots, frames)
+    model.synchronize()
+    logits, _, hidden, last = model.debug_taps(n)
+    fast = model.fast_trace(n) if trace else last
+    toks = [model.read(i)[0].clone() for i in slots]
+    for i in slots:
+        model.release(i)
+    model.set_trace(False)
+    model.set_graph(True)
+    bits = lambda t: t.contiguous().view(torch.int16).cpu()   # noqa: E731
+    return toks, bits(logits), bits(hidden), bits(fast)
+
+
+@pytest.mark.parametrize("B", [5, 8])
+def test_merged_fast_positions_equal_the_two_pass_path_bit_for_bit_at_batch_5_and_8(B):
+    """with 5..8 utterances the merged pass runs the fast GEMVs at M = 2 B = 10..16 rows -- the 16-row
+    forms, whose SwiGLU variant takes its RMSNorm statistics in another kernel branch than the <= 8-row form of the two-pass
+    path.  Both branches now share one partition and reduction tree; asserted on the FLOAT taps, not only on tokens:
+    slow logits, hidden rows and the logits of all ten fast positions of the last frame are bit-identical with the
+    merge on and off, as are the token matrices (and the rebuilt key / value 0 of fast_attn_kernel's merged form with
+    them: any difference there would move the position-1 logits)."""
+    skw, prompts, seeds = _ragged_prompts()
+    cfg, model, _ = _model(skw)
+    for trace in (True, False):
+        outs = {}
+        for merge in (True, False):
+            model.set_fast_merge(merge)
+            outs[merge] = _run_with_taps(model, prompts[:B], seeds[:B], frames=6, trace=trace)
+        model.set_fast_merge(True)
+        (t1, l1, h1, f1), (t0, l0, h0, f0) = outs[True], outs[False]
+        for a, b in zip(t1, t0):
+            assert torch.equal(a, b)
+        assert torch.equal(l1, l0) and torch.equal(h1, h0), "slow taps differ between the merged and the two-pass frame"
+        assert torch.equal(f1, f0), f"trace={trace}: fast logits differ at {torch.nonzero(f1 != f0)[:4].tolist()}"
+        assert int(f1.ne(0).sum()) > 0
+
+
+def test_rows_are_bit_identical_in_a_batch_of_8_and_in_a_batch_of_16():
+    """Batch invariance across the M = 8 / M = 16 kernel forms, on the float taps: the eight ragged
+    utterances alone, and twice over in a batch of 16 (slots i and i + 8 carry the same utterance) -- slow layers at
+    M = 16 (XR = 16 forms, SwiGLU without held fragments), fast positions unmerged above batch 8.  Every row's slow
+    logits, hidden state and fast logits equal its batch-8 bits."""
+    skw, prompts, seeds = _ragged_prompts()
+    cfg, model, _ = _model(skw)
+    t8, l8, h8, f8 = _run_with_taps(model, prompts, seeds, frames=4)
+    t16, l16, h16, f16 = _run_with_taps(model, prompts + prompts, seeds + seeds, frames=4)
+    for i in range(8):
+        assert torch.equal(t16[i], t8[i]) and torch.equal(t16[i + 8], t8[i]), i
+    for half in (slice(0, 8), slice(8, 16)):
+        assert torch.equal(l16[half], l8) and torch.equal(h16[half], h8), "slow taps depend on the batch size"
+        assert torch.equal(f16[half], f8), "fast logits depend on the batch size"
 
 
 def test_s2_int8_full_sequence_equals_the_reference_int8_run():
