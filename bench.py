@@ -229,11 +229,12 @@ def run_steps_overlapped(model, codec, prompts, samp_seeds, device, steps, side)
     return frame_ms, wav
 
 
-def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=32, codec_frames=N_FRAMES):
+def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=64, codec_frames=N_FRAMES):
     """The oracle (CPU restatement of the reference path, kind 'port') timed on this box's host cores on a
     bounded sample of the same workload: Dual-AR prefill of one 200-token prompt + n_frames decode frames at context
-    200.. (batch 1 -- the reference cannot batch), extrapolated linearly to 215 frames, and the codec decode of the
-    FULL 215 frames of one utterance."""
+    200.. (batch 1 -- the reference cannot batch), timed in two halves so that the growth of a frame with its context
+    is measured, not assumed; extrapolated along that trend to 215 frames (the flat extrapolation is reported beside it),
+    and the codec decode of the FULL 215 frames of one utterance."""
     from oracle import dac as OD
     from oracle import dual_ar as O
 
@@ -258,11 +259,19 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=32, codec_frames=N_FR
     t0 = time.perf_counter()
     O.generate(orc, prompt, 1, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
     t_prefill = time.perf_counter() - t0
+    half = n_frames // 2
+    t0 = time.perf_counter()
+    O.generate(orc, prompt, 1 + half, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
+    t_half = time.perf_counter() - t0
     t0 = time.perf_counter()
     O.generate(orc, prompt, 1 + n_frames, 0.7, 0.7, 30, uniform_fn=O.FmiUniform(1, 0), stop_on_im_end=False)
     t_all = time.perf_counter() - t0
     per_frame = max(t_all - t_prefill, 1e-9) / n_frames
-    t_ar = t_prefill + (N_FRAMES - 1) * per_frame
+    pf_a = max(t_half - t_prefill, 1e-9) / half                  # frames [0, half): mean context PROMPT_T + half / 2
+    pf_b = max(t_all - t_half, 1e-9) / (n_frames - half)         # frames [half, n): mean context PROMPT_T + 3 half / 2
+    slope = (pf_b - pf_a) / half                                  # seconds per frame per frame of context
+    t_flat = t_prefill + (N_FRAMES - 1) * per_frame
+    t_ar = t_prefill + sum(max(pf_a + slope * (i - half / 2), 0.0) for i in range(N_FRAMES - 1))
     del orc, st
     t_codec, note, cbest = 0.0, "codec not included", best
     if codec_state_dev is not None:
@@ -294,8 +303,9 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=32, codec_frames=N_FR
                   f"is not on this box), torch CPU, batch 1, Dual-AR on {best} threads (best of sweep "
                   f"{ {k: round(v, 2) for k, v in sweep.items()} } s/frame-ish, host has {os.cpu_count()} cpus): "
                   f"prefill {PROMPT_T} tokens {t_prefill:.2f}s + {n_frames} decode "
-                  f"frames at context {PROMPT_T}..{PROMPT_T + n_frames} at {per_frame:.3f}s/frame (bf16), extrapolated to "
-                  f"{N_FRAMES} frames; {note}",
+                  f"frames at context {PROMPT_T}..{PROMPT_T + n_frames} at {per_frame:.3f}s/frame (bf16; first half "
+                  f"{pf_a:.3f}, second half {pf_b:.3f}), extrapolated along that trend to {N_FRAMES} frames = {t_ar:.1f}s "
+                  f"(flat extrapolation {t_flat:.1f}s, {100 * (t_flat / t_ar - 1):+.1f} %); {note}",
     }
 
 
@@ -458,6 +468,28 @@ def run_batch16(model, codec, cfg, device):
     return {"batch_per_gpu": 16, "audio_sec_per_s": round(16 * N_FRAMES * FRAME_LEN / SAMPLE_RATE / dt, 2),
             "ms_per_step": round(dt * 1e3, 1), "decode_frame_avg_ms": round(ms / (N_FRAMES - 1), 4),
             "launches_per_frame": launches, "note": "codec decode of the 16 utterances inside the step; not the headline"}
+
+
+def run_overlapped(model, codec, prompts, seeds, device, steps=3):
+    """VERDICT r04 #2, reported beside the serial step so rounds stay comparable: the same step with the codec decode of
+    batch i - 1 running BESIDE the frame loop of batch i (run_steps_overlapped).  Measured after the timed region; NOT what
+    `value` is: on this hardware the two queues time-slice the CUs (a conv work-group holds half a CU's registers for
+    milliseconds, the loop's 6-20 us GEMVs queue behind it) and the frames lose what the codec gains
+    (profiles/r05_overlap_step.txt, r05_overlap_floor.txt)."""
+    side = torch.cuda.Stream(device=device)
+    codec.set_async(True)
+    try:
+        run_steps_overlapped(model, codec, prompts, seeds, device, 1, side)
+        _sync(device)
+        t0 = time.perf_counter()
+        fms, _ = run_steps_overlapped(model, codec, prompts, seeds, device, steps, side)
+        _sync(device)
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        codec.set_async(False)
+    return {"ms_per_step": round(dt * 1e3, 2), "audio_sec_per_s": round(BATCH * N_FRAMES * FRAME_LEN / SAMPLE_RATE / dt, 2),
+            "decode_frame_avg_ms": round(sum(fms) / len(fms), 4), "steps": steps,
+            "note": "codec decode of batch i-1 on its own stream beside the frame loop of batch i; measured and not adopted"}
 
 
 def run_config1(model, codec, cfg, device):
@@ -712,6 +744,11 @@ def main():
                      "frac": round(achieved / 8000.0, 4),
                      "traffic": pmc_traffic(BATCH, N_FRAMES, args.int8)[0],
                      "traffic_source": pmc_traffic(BATCH, N_FRAMES, args.int8)[1],
+                     # what the binary really moved per frame (PMC) / the same time / the same peak: fast positions 0 and 1
+                     # share a pass over the fast weights since round 4, so it streams LESS than the SURVEY 8d formula
+                     # `achieved` divides by the same time -- `frac` credits bytes that are no longer read
+                     "traffic_frac": (round(pmc_traffic(BATCH, N_FRAMES, args.int8)[0] / avg_frame_s / 1e9 / 8000.0, 4)
+                                      if pmc_traffic(BATCH, N_FRAMES, args.int8)[0] else None),
                      "kernel": f"decode frame: {launches} launches replayed as one hipGraph -- linear_skinny_kernel (weight "
                                "streaming: 36 slow layers x 4 + the fast transformer's 9 passes x 4 layers x 4 + heads), 36 "
                                "attention, 36 fast-attention, 10 sampler launches",
@@ -732,6 +769,7 @@ def main():
             extras["config4_streaming"] = run_config5(model, codec, cfg, device)
             extras["config4_streaming_staggered_arrivals"] = run_config5_staggered(model, codec, cfg)
             extras["batch16"] = run_batch16(model, codec, cfg, device)
+            extras["overlapped_step"] = run_overlapped(model, codec, prompts, seeds, device)
         out["other_configs"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, state, codec_state)

@@ -92,6 +92,7 @@ _SIGS = {
     "fmi_dac_weights_ready": (C.c_int, [_P]),
     "fmi_dac_set_precision": (C.c_int, [_P, _I]),
     "fmi_dac_set_async": (C.c_int, [_P, _I]),
+    "fmi_dac_set_background": (C.c_int, [_P, _I]),
     "fmi_dac_wait": (C.c_int, [_P, _P]),
     "fmi_dac_synchronize": (C.c_int, [_P]),
     "fmi_dac_set_stream_options": (C.c_int, [_P, _I, _I, C.POINTER(C.c_uint32)]),

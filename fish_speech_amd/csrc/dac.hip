@@ -109,6 +109,7 @@ struct fmi_dac {
   hipStream_t stream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   bool async_out = false;   // fmi_dac_set_async
+  int lds_floor = 0;        // fmi_dac_set_background
   int* f16_ovf = nullptr;   // device word: an operand of the fp16-split arithmetic left the fp16 range (fmi_dac_fp16_overflow)
   Buf buf[6];
   void* staging = nullptr;
@@ -381,6 +382,7 @@ int ensure_buf(fmi_dac* h, int i, int64_t n) {
 
 int sync_in(fmi_dac* h, void* us) {
   set_f16_overflow_target(h->f16_ovf);   // every entry point comes through here, under h->mu: its kernels flag THIS handle
+  set_conv_lds_floor(h->lds_floor);
   FMI_CHECK_HIP(hipEventRecord(h->ev_in, (hipStream_t)us));
   FMI_CHECK_HIP(hipStreamWaitEvent(h->stream, h->ev_in, 0));
   return FMI_OK;
@@ -936,6 +938,15 @@ int fmi_dac_set_async(fmi_dac* h, int enable) {
   if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
   FMI_REQUIRE(h, "null handle");
   h->async_out = enable != 0;
+  return FMI_OK;
+}
+
+int fmi_dac_set_background(fmi_dac* h, int lds_floor_bytes) {
+  std::unique_lock<std::mutex> lock_;
+  if (h) lock_ = std::unique_lock<std::mutex>(h->mu);
+  FMI_REQUIRE(h, "null handle");
+  FMI_REQUIRE(lds_floor_bytes >= 0 && lds_floor_bytes <= 160 * 1024, "LDS floor must be in [0, 160 KiB]");
+  h->lds_floor = lds_floor_bytes;
   return FMI_OK;
 }
 

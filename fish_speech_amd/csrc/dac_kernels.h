@@ -119,6 +119,8 @@ int launch_vq_step(const VqArgs& a, hipStream_t s);
 // wrappers of THIS host thread hand to their kernels (an entry point sets it under its handle's mutex; nullptr = a
 // process-wide word nobody reads); read_clear waits for `s`, returns the word and clears it.
 void set_f16_overflow_target(int* dev_word);
+// floor (bytes, <= 160 KiB) under the dynamic LDS of this host thread's conv_mfma_bf16 launches; 0 = none
+void set_conv_lds_floor(int bytes);
 int read_clear_f16_overflow(int* dev_word, int* flag, hipStream_t s);
 
 }  // namespace fmi

@@ -688,14 +688,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
   }
 }
 
+// "Background" occupancy of the decode-side conv kernels (fmi_dac_set_background): a floor under the dynamic LDS a launch
+// asks for.  Above 80 KiB only ONE work-group of these kernels fits a CU (4 waves x <= 256 registers = half of the
+// register file, the other half and >= 75 KiB of LDS stay free), so that the work-groups of ANOTHER queue -- the Dual-AR
+// frame loop's 8-wave GEMVs at 72-80 registers -- can be co-resident instead of waiting for a conv work-group to retire.
+static thread_local int t_conv_lds_floor = 0;
+void set_conv_lds_floor(int bytes) { t_conv_lds_floor = bytes; }
+
 // transposed conv, phase-tiled (conv_mfma_bf16_kernel<..., PH = true>): MT phases x 32 channels per work-group
 template <int MT, int G, int NP>
 static int launch_conv_bf16_ph(const ConvArgs& a, int ncols, int tap_off0, int span, hipStream_t s) {
   const ConvW& w = a.w;
   constexpr int TT = 128, CO_T = MT * 32;
   const int wx = (TT - 1) * a.x_stride + span;
-  const size_t smem = (size_t)(G * NP * wx + w.taps * G * NP * CO_T) * 32;
+  size_t smem = (size_t)(G * NP * wx + w.taps * G * NP * CO_T) * 32;
   FMI_REQUIRE(smem <= 160 * 1024, "conv(bf16, phases): LDS tile of %zu bytes exceeds 160 KiB", smem);
+  if (smem < (size_t)t_conv_lds_floor) smem = (size_t)t_conv_lds_floor;
   FMI_REQUIRE(w.phases % MT == 0 && w.cout_pad % 32 == 0 && (w.cin_pad16 >> 4) % G == 0, "conv(bf16, phases): bad tiling");
   dim3 grid(cdiv(ncols, TT), w.cout_pad / 32, a.B * (w.phases / MT)), block(256);
   if (smem > 64 * 1024)
@@ -712,8 +720,9 @@ static int launch_conv_bf16_tt(const ConvArgs& a, int ncols, int tap_off0, int s
   constexpr int TT = 4 * NT * 32, CO_T = MT * 32;
   const int wx = (TT - 1) * a.x_stride + span;
   const int wt = TC > 0 ? TC : w.taps;
-  const size_t smem = (size_t)(G * NP * wx + wt * G * NP * CO_T) * 32;
+  size_t smem = (size_t)(G * NP * wx + wt * G * NP * CO_T) * 32;
   FMI_REQUIRE(smem <= 160 * 1024, "conv(bf16): LDS tile of %zu bytes exceeds 160 KiB", smem);
+  if (smem < (size_t)t_conv_lds_floor) smem = (size_t)t_conv_lds_floor;
   FMI_REQUIRE(w.cout_pad % CO_T == 0 && (w.cin_pad16 >> 4) % G == 0, "conv(bf16): tile does not divide the packed weight");
   dim3 grid(cdiv(ncols, TT), w.cout_pad / CO_T, a.B * w.phases), block(256);
   if (smem > 64 * 1024)

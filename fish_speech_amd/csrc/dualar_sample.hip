@@ -356,6 +356,7 @@ struct SmallShared {
   __attribute__((aligned(16))) float s_val[64];
   int s_idx[64];
   uint32_t wc[4][64];   // per wave: its k candidates as key << 16 | ~index, then sorted descending
+  int bkw[4][32];       // per wave: how many of its keys lie 16 j .. 16 j + 15 key units below the block maximum
 };
 
 // suffix[b] = sum_{j >= b} hist[j] evaluated by wave 0; returns via sel[o], sel[o+1] the bin where the
@@ -425,9 +426,21 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   SmallShared& sh = *reinterpret_cast<SmallShared*>(smem_raw);
   uint16_t* skey = reinterpret_cast<uint16_t*>(smem_raw + sizeof(SmallShared));
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int slot = a.row_slot ? a.row_slot[b] : b;
   const bf16_t* lg = a.logits + (int64_t)b * a.ld;
   const int n = a.n;
+  if (a.dbg_stop == 1) return;
+
+  // ---- pass 1: coalesced loads (element tid + 256 j), keys to LDS, block max
+  // (all 17 loads requested before the first is used -- clamped index, then a select: behind the `i < n` branch each
+  // load had its own s_waitcnt vmcnt(0), seventeen dependent L2 round trips at the top of every sampler launch.
+  // Round 5: they are also requested BEFORE the slot's parameters, which they do not depend on -- slot index, then six
+  // state words, then the wait for top_k used to stand in front of them: two more round trips, to memory another XCD's
+  // sampler wrote, before the first logit was even asked for)
+  bf16_t lraw[SMALL_EPT];
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j) lraw[j] = lg[min(tid + 256 * j, n - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  const int slot = a.row_slot ? a.row_slot[b] : b;
 
   float temperature, top_p;
   int top_k, frame, draw0, use_ras;
@@ -441,19 +454,9 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     draw0 = (a.mode == 0) ? 0 : 1 + a.cb;
     use_ras = a.st.use_ras[slot] && frame > 0;
   }
-  int k = top_k < n ? top_k : n;
-  if (k > 64) k = 64;
-  if (k < 1) k = 1;
-  if (a.dbg_stop == 1) return;
 
-  // ---- pass 1: coalesced loads (element tid + 256 j), keys to LDS, block max
   float xv[SMALL_EPT];
   uint32_t kmax = 0;
-  // (all 17 loads requested before the first is used -- clamped index, then a select: behind the `i < n` branch each
-  // load had its own s_waitcnt vmcnt(0), seventeen dependent L2 round trips at the top of every sampler launch)
-  bf16_t lraw[SMALL_EPT];
-#pragma unroll
-  for (int j = 0; j < SMALL_EPT; ++j) lraw[j] = lg[min(tid + 256 * j, n - 1)];
 #pragma unroll
   for (int j = 0; j < SMALL_EPT; ++j) {
     const int i = tid + 256 * j;
@@ -467,11 +470,16 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   }
   kmax = wave_max_dpp_u(kmax);
   if (lane == 0) sh.wmax[wave] = kmax;
+  if (tid < 128) (&sh.bkw[0][0])[tid] = 0;
+  if (wave == 0) sh.wc[0][lane] = 0;     // (the one shared candidate list of the short path below)
   __syncthreads();
   kmax = max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
   const bf16_t maxbits = (kmax & 0x8000) ? (bf16_t)(kmax & 0x7fff) : (bf16_t)(~kmax & 0xffff);
   const float vmax = bf2f(maxbits);
   if (a.dbg_stop == 2) return;
+  int k = top_k < n ? top_k : n;
+  if (k > 64) k = 64;
+  if (k < 1) k = 1;
   // softmax denominator over ALL entries, same summation order as sample_kernel (thread-strided
   // partials j = 0.., xor tree per wave, waves summed 0..3)
   float se = 0.f;
@@ -487,9 +495,50 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
 #pragma unroll
   for (int j = 0; j < SMALL_EPT; ++j) kr[j] = (j < ept && i0 + j < n) ? (uint32_t)skey[i0 + j] : 0u;
   // (key 0 never occurs for a real entry: order_key(x) >= 0x007f for -inf and above)
+  // Round 5: where do the k largest keys END?  Every wave counts its keys by their distance below the block maximum, in
+  // 32 buckets of 16 key units (one octave of a bf16 is 128 units: four octaves) -- an LDS add per key that is in range,
+  // and at most a few hundred of the 4097 are.  After the barrier every wave knows the smallest distance that already
+  // holds k keys of the WHOLE row: nothing farther from the maximum can be among the k largest, so the waves only hand
+  // on their keys inside that distance instead of each finding its own k largest by an eight-step radix descent.
+#pragma unroll
+  for (int j = 0; j < SMALL_EPT; ++j) {
+    const uint32_t d = kmax - kr[j];
+    if (kr[j] != 0u && d < 512u) atomicAdd(&sh.bkw[wave][d >> 4], 1);
+  }
   __syncthreads();
   const float sumexp = sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3];
   if (a.dbg_stop == 3) return;
+  // bucket j of lane j (every wave evaluates this identically: no further barrier): inclusive prefixes over the buckets of
+  // the row total, of this wave's own count and of the counts of the waves before it
+  int jstar = -1, g_sel = 0, c_me = 0, c_base = 0;
+  if (a.short_path) {
+    const int bj = lane & 31;
+    const int b0 = sh.bkw[0][bj], b1 = sh.bkw[1][bj], b2 = sh.bkw[2][bj], b3 = sh.bkw[3][bj];
+    int pg = b0 + b1 + b2 + b3;
+    int pm = wave == 0 ? b0 : (wave == 1 ? b1 : (wave == 2 ? b2 : b3));
+    int pb = wave == 0 ? 0 : (wave == 1 ? b0 : (wave == 2 ? b0 + b1 : b0 + b1 + b2));
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int vg = __shfl_up(pg, off, 32), vm = __shfl_up(pm, off, 32), vb = __shfl_up(pb, off, 32);
+      if (bj >= off) {
+        pg += vg;
+        pm += vm;
+        pb += vb;
+      }
+    }
+    const uint32_t reach = (uint32_t)(__ballot(pg >= k) & 0xffffffffull);   // lanes 0-31: buckets whose prefix holds k keys
+    if (reach) {
+      jstar = __ffs((int)reach) - 1;
+      g_sel = __builtin_amdgcn_readlane(pg, jstar);
+      c_me = __builtin_amdgcn_readlane(pm, jstar);
+      c_base = __builtin_amdgcn_readlane(pb, jstar);
+    }
+  }
+  // one: the whole row has at most 64 keys inside the distance -> ONE shared list, sorted once by wave 0 (no per-wave sorts,
+  // no merges); per_wave: more than 64 in the row, at most 64 in this wave -> the wave's list holds them all (the merge
+  // keeps the 64 largest); otherwise this wave falls back to the descent (ties by the thousand, k beyond the reach).
+  const bool one = jstar >= 0 && g_sel <= 64;
+  const bool per_wave = jstar >= 0 && !one && c_me <= 64;
 
   // ---- top-k without block-wide rounds.  Every wave picks the k largest of ITS keys by a radix-4 descent whose
   // counts meet inside the wave (DPP reductions, no LDS, no barrier), compacts them in index order (ties on the
@@ -499,6 +548,10 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   // other is bitonic and holds the 64 largest of both: six more stages sort it).  One barrier in total; lane r of
   // wave 0 ends up with the rank-r candidate.
   uint32_t thr = 0;
+  if (one || per_wave) {   // keys >= kmax - (16 (jstar + 1) - 1), i.e. strictly above thr
+    const int t0 = (int)kmax - (16 * (jstar + 1) - 1);
+    thr = t0 > 1 ? (uint32_t)(t0 - 1) : 0u;
+  } else {
 #pragma unroll 1
   for (int step = 0; step < 8; ++step) {
     const int sh_bits = 14 - 2 * step;
@@ -517,11 +570,13 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     else if (t2 >= k) thr = c2;
     else if (t1 >= k) thr = c1;
   }
+  }
+  const bool take_eq = !(one || per_wave);   // the short paths take every key above thr and none equal to it
   int my_gt = 0, my_eq = 0;
 #pragma unroll
   for (int j = 0; j < SMALL_EPT; ++j) {
     my_gt += kr[j] > thr;
-    my_eq += (kr[j] == thr) && (thr != 0);
+    my_eq += (kr[j] == thr) && (thr != 0) && take_eq;
   }
   if (a.dbg_stop == 4) return;
   int inc_gt = my_gt, inc_eq = my_eq;
@@ -533,39 +588,47 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
       inc_eq += e;
     }
   }
-  const int c_gt = __builtin_amdgcn_readlane(inc_gt, 63);     // this wave's keys above its threshold (< k)
+  const int c_gt = __builtin_amdgcn_readlane(inc_gt, 63);     // this wave's keys above its threshold (< k; short paths: <= 64)
   const int need_eq = k - c_gt;
-  int off_gt = inc_gt - my_gt, off_eq = inc_eq - my_eq;
-  uint32_t* wc = sh.wc[wave];
-  wc[lane] = 0;                                                 // word 0 = empty place (real words have key >= 0x7f)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  int off_gt = inc_gt - my_gt + (one ? c_base : 0), off_eq = inc_eq - my_eq;
+  uint32_t* wc = one ? sh.wc[0] : sh.wc[wave];                // `one`: every wave appends to the shared list (zeroed above)
+  if (!one) {
+    wc[lane] = 0;                                               // word 0 = empty place (real words have key >= 0x7f)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
 #pragma unroll
   for (int j = 0; j < SMALL_EPT; ++j) {
     const uint32_t key = kr[j];
     const uint32_t word = (key << 16) | (uint32_t)(0xffff - (i0 + j));
     if (key > thr) {
       wc[off_gt++] = word;
-    } else if (key == thr && thr != 0) {
+    } else if (key == thr && thr != 0 && take_eq) {
       if (off_eq < need_eq) wc[c_gt + off_eq] = word;
       ++off_eq;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  uint32_t w = wc[lane];
   // bitonic sort, descending over the 64 lanes
+  auto sort64 = [&](uint32_t w) -> uint32_t {
 #pragma unroll
-  for (int size = 2; size <= 64; size <<= 1)
+    for (int size = 2; size <= 64; size <<= 1)
 #pragma unroll
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)w, stride, 64);
-      const bool take_max = ((lane & stride) == 0) == ((lane & size) == 0);
-      w = take_max ? max(w, o) : min(w, o);
-    }
-  wc[lane] = w;
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)w, stride, 64);
+        const bool take_max = ((lane & stride) == 0) == ((lane & size) == 0);
+        w = take_max ? max(w, o) : min(w, o);
+      }
+    return w;
+  };
+  uint32_t w = 0;
+  if (!one) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    w = sort64(wc[lane]);
+    wc[lane] = w;
+  }
   __syncthreads();
   // the rows gathered for the next fast step (embedding, tabulated layer-0 q|k|v) are fetched by ALL waves once wave 0
   // knows the code: 17 dependent load -> store trips of one wave (5 + 12 KB at the S2 shape) were ~10 us of this kernel
@@ -581,10 +644,15 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     }
     return m;
   };
-  const uint32_t m01 = merge_desc(w, sh.wc[1][63 - lane]);
-  const uint32_t m23 = merge_desc(sh.wc[2][lane], sh.wc[3][63 - lane]);
-  const uint32_t m23_rev = (uint32_t)__shfl((int)m23, 63 - lane, 64);
-  const uint32_t top = merge_desc(m01, m23_rev);
+  uint32_t top;
+  if (one) {
+    top = sort64(sh.wc[0][lane]);
+  } else {
+    const uint32_t m01 = merge_desc(w, sh.wc[1][63 - lane]);
+    const uint32_t m23 = merge_desc(sh.wc[2][lane], sh.wc[3][63 - lane]);
+    const uint32_t m23_rev = (uint32_t)__shfl((int)m23, 63 - lane, 64);
+    top = merge_desc(m01, m23_rev);
+  }
 
   // ---- wave 0: lane r holds the rank-r candidate; sequential cumsum evaluated by every lane
   const bool in = lane < k;
@@ -653,17 +721,20 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     // ... and the first fast layer's q|k|v of that code (precomputed with the very same GEMV); every load of a
     // thread is requested before its first store
     const int n1 = a.fdim >> 3, n2 = a.qkv0_tab ? (a.qkv0_dim >> 3) : 0;
-    const uint4* src1 = reinterpret_cast<const uint4*>(a.fast_emb + (int64_t)tok * a.fdim);
-    const uint4* src2 = a.qkv0_tab ? reinterpret_cast<const uint4*>(a.qkv0_tab + (int64_t)tok * a.qkv0_dim) : nullptr;
-    uint4* dst1 = reinterpret_cast<uint4*>(a.xf + (int64_t)b * a.fdim);
-    uint4* dst2 = a.qkv0_tab ? reinterpret_cast<uint4*>(a.qkv0_out + (int64_t)b * a.qkv0_dim) : nullptr;
+    // (vector types, not HIP's uint4 struct: copies of the struct went through SCRATCH -- 112 bytes per lane, every row
+    // piece stored right behind its load and re-loaded for the store, so the loads were not in flight together)
+    const u32x4* src1 = reinterpret_cast<const u32x4*>(a.fast_emb + (int64_t)tok * a.fdim);
+    const u32x4* src2 = a.qkv0_tab ? reinterpret_cast<const u32x4*>(a.qkv0_tab + (int64_t)tok * a.qkv0_dim) : nullptr;
+    u32x4* dst1 = reinterpret_cast<u32x4*>(a.xf + (int64_t)b * a.fdim);
+    u32x4* dst2 = a.qkv0_tab ? reinterpret_cast<u32x4*>(a.qkv0_out + (int64_t)b * a.qkv0_dim) : nullptr;
     const int nthr = gather_all ? 256 : 64, t0 = gather_all ? tid : lane;
     constexpr int GB = 6;
     for (int base = 0; base < n1 + n2; base += GB * nthr) {
-      uint4 gv[GB];
+      u32x4 gv[GB];
 #pragma unroll
       for (int j = 0; j < GB; ++j) {
         const int i = base + t0 + j * nthr;
+        gv[j] = (u32x4){0u, 0u, 0u, 0u};
         if (i < n1) gv[j] = src1[i];
         else if (i < n1 + n2) gv[j] = src2[i - n1];
       }
@@ -705,7 +776,10 @@ int launch_sample(const SampleArgs& a, hipStream_t s) {
   FMI_REQUIRE(a.n >= 1 && a.n <= 65536, "sample: n=%d out of range", a.n);
   if (a.small_k && a.n <= 256 * SMALL_EPT) {  // every slot draws with top_k <= 64, keys fit in registers
     size_t smem = sizeof(SmallShared) + (size_t)a.n * 2 + 16;
-    hipLaunchKernelGGL(sample_small_kernel, dim3(a.B), dim3(256), smem, s, a);
+    static const bool descent = []() { const char* e = getenv("FMI_SAMPLE_DESCENT"); return e && atoi(e) != 0; }();
+    SampleArgs b = a;
+    b.short_path = descent ? 0 : 1;
+    hipLaunchKernelGGL(sample_small_kernel, dim3(a.B), dim3(256), smem, s, b);
     FMI_CHECK_HIP(hipGetLastError());
     return FMI_OK;
   }

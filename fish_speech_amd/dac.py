@@ -325,6 +325,12 @@ class MiDAC:
         self._async = bool(enable)
         return self
 
+    def set_background(self, lds_floor_bytes: int):
+        """Floor under the dynamic LDS of the decode-side conv kernels (> 80 KiB: one work-group per CU, so that another
+        queue's work-groups can be co-resident); 0 = off."""
+        check(self.lib.fmi_dac_set_background(self._h, int(lds_floor_bytes)))
+        return self
+
     def wait_stream(self):
         """order torch's current stream after the codec calls enqueued so far (no host wait)"""
         check(self.lib.fmi_dac_wait(self._h, self._stream()))

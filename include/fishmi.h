@@ -291,7 +291,11 @@ int fmi_dac_fp16_overflow(fmi_dac* h, int* overflowed);
  *     fmi_dac_synchronize(h), and keeps the input / output buffers alive until then.
  *   fmi_dac_set_stream_options: re-creates the handle's stream with a dispatch priority (-1 highest, 0 default,
  *     1 lowest) or, when cu_mask_words > 0, with a CU mask (bit i = compute unit i may run this handle's kernels;
- *     hipExtStreamCreateWithCUMask) -- the codec can be confined to part of the chip while the loop keeps the rest. */
+ *     hipExtStreamCreateWithCUMask) -- the codec can be confined to part of the chip while the loop keeps the rest.
+ *   fmi_dac_set_background(h, bytes): a floor under the dynamic LDS of the decode-side conv kernels; above 80 KiB only one
+ *     of their work-groups fits a CU, so the frame loop's work-groups can be co-resident instead of queueing behind them
+ *     (0 = off, the default: two to three conv work-groups per CU). */
+int fmi_dac_set_background(fmi_dac* h, int lds_floor_bytes);
 int fmi_dac_set_async(fmi_dac* h, int enable);
 int fmi_dac_wait(fmi_dac* h, void* stream);
 int fmi_dac_synchronize(fmi_dac* h);

@@ -426,6 +426,37 @@ def test_fp16_overflow_flag_belongs_to_the_handle_that_overflowed(small):
     assert sid not in safe._fp32_streams
 
 
+def test_async_calls_stream_options_and_background_occupancy_leave_the_waveform_unchanged(small):
+    """Round 5 (fishmi.h: fmi_dac_set_async / _wait / _synchronize / _set_stream_options / _set_background): a decode that
+    is only ENQUEUED on the codec's stream (the caller waits or orders itself later), on a stream re-created with a
+    priority or a CU mask, with the conv kernels held to one work-group per CU -- scheduling knobs, never arithmetic:
+    every variant returns the bits of the plain call."""
+    cfg, state, z, codec = small
+    codes = D.make_codes(cfg, 2, 9, seed=21).to(DEV)
+    want = codec.from_indices(codes.clone())
+    try:
+        codec.set_async(True)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            got = codec.from_indices(codes.clone())
+        codec.synchronize()
+        assert torch.equal(got, want)
+        got = codec.from_indices(codes.clone())
+        codec.wait_stream()                      # torch's stream ordered after the decode: a consumer kernel is safe
+        assert torch.equal(got.clone(), want)
+        codec.set_async(False)
+        for opt in (dict(priority=1), dict(priority=-1), dict(cu_mask=[0xFFFFFFFF]), dict(priority=0)):
+            codec.set_stream_options(**opt)
+            assert torch.equal(codec.from_indices(codes.clone()), want), opt
+        for floor in (84 * 1024, 0):
+            codec.set_background(floor)
+            assert torch.equal(codec.from_indices(codes.clone()), want), floor
+    finally:
+        codec.set_async(False)
+        codec.set_background(0)
+        codec.set_stream_options(priority=0)
+
+
 def test_concurrent_from_indices_from_request_threads(small):
     """request threads share the codec object (tools/api_server.py:115-122 -> get_audio_segment).  Four
     threads decode different codes at once, some inside autocast: every result equals the sequential one."""

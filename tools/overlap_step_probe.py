@@ -74,32 +74,55 @@ def main():
 
     codes = serial("serial (bench.py r04)")
     want = codec.from_indices(codes.clone())
-    wav = overlapped("overlapped, plain streams")
-    assert torch.equal(wav, want), "the overlapped step's waveform differs from the serial step's"
-    model.set_stream_priority(-1)
-    codec.set_stream_options(priority=1)
-    overlapped("overlapped, frame loop high / codec low priority")
-    serial("serial, same priorities (control)")
-    model.set_stream_priority(0)
+    modes = sys.argv[2] if len(sys.argv) > 2 else "plain,prio,mask,floor"
+    if "plain" in modes:
+        wav = overlapped("overlapped, plain streams")
+        assert torch.equal(wav, want), "the overlapped step's waveform differs from the serial step's"
+    if "prio" in modes:
+        model.set_stream_priority(-1)
+        codec.set_stream_options(priority=1)
+        overlapped("overlapped, frame loop high / codec low priority")
+        serial("serial, same priorities (control)")
+        model.set_stream_priority(0)
+        codec.set_stream_options(priority=0)
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    for name, bits in (("first 16 CUs", range(16)), ("first 32 CUs", range(32)), ("first 64 CUs", range(64)),
-                       ("every 8th CU (32)", range(0, n_cu, 8)), ("every 4th CU (64)", range(0, n_cu, 4)),
-                       ("every 2nd CU (128)", range(0, n_cu, 2))):
-        codec.set_stream_options(cu_mask=mask_words(bits))
-        wav = overlapped(f"overlapped, codec confined to {name}")
-        assert torch.equal(wav, want)
-    # the codec alone under a mask: how much longer does the decode take on part of the chip
-    for name, bits in (("first 32 CUs", range(32)), ("every 4th CU (64)", range(0, n_cu, 4))):
-        codec.set_stream_options(cu_mask=mask_words(bits))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        codec.from_indices(codes.clone())
-        e0.record()
-        codec.from_indices(codes.clone())
-        e1.record()
-        e1.synchronize()
-        print(f"codec decode alone, confined to {name}: {e0.elapsed_time(e1):.2f} ms", flush=True)
-    codec.set_stream_options(priority=0)
+    if "mask" in modes:
+        for name, bits in (("first 16 CUs", range(16)), ("first 32 CUs", range(32)), ("first 64 CUs", range(64)),
+                           ("every 8th CU (32)", range(0, n_cu, 8)), ("every 4th CU (64)", range(0, n_cu, 4)),
+                           ("every 2nd CU (128)", range(0, n_cu, 2))):
+            codec.set_stream_options(cu_mask=mask_words(bits))
+            wav = overlapped(f"overlapped, codec confined to {name}")
+            assert torch.equal(wav, want)
+        # the codec alone under a mask: how much longer does the decode take on part of the chip
+        for name, bits in (("first 32 CUs", range(32)), ("every 4th CU (64)", range(0, n_cu, 4))):
+            codec.set_stream_options(cu_mask=mask_words(bits))
+            print(f"codec decode alone, confined to {name}: {codec_alone(codec, codes):.2f} ms", flush=True)
+        codec.set_stream_options(priority=0)
+    if "floor" in modes:
+        # one conv work-group per CU (LDS floor > 80 KiB): the frame loop's GEMV work-groups can be co-resident
+        for kib in (56, 84, 120):
+            codec.set_background(kib * 1024)
+            print(f"codec decode alone, conv LDS floor {kib} KiB: {codec_alone(codec, codes):.2f} ms", flush=True)
+            wav = overlapped(f"overlapped, conv LDS floor {kib} KiB")
+            assert torch.equal(wav, want)
+        codec.set_background(84 * 1024)
+        model.set_stream_priority(-1)
+        codec.set_stream_options(priority=1)
+        overlapped("overlapped, conv LDS floor 84 KiB + loop high / codec low")
+        model.set_stream_priority(0)
+        codec.set_stream_options(priority=0)
+        codec.set_background(0)
     serial("serial again (default streams)")
+
+
+def codec_alone(codec, codes):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    codec.from_indices(codes.clone())
+    e0.record()
+    codec.from_indices(codes.clone())
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
 
 
 if __name__ == "__main__":
