@@ -350,7 +350,7 @@ def prefill_roofline(cfg, prefill_ms):
 
 def codec_roofline(codec_ms):
     """Codec decode of 8 x 215 frames on the fp16 matrix cores: useful flops (1.454 TFLOP per 215-frame
-    utterance) and issued flops (the two-term fp16 split runs 3 MFMA products per useful one, DESIGN section 4)."""
+    utterance) and issued flops (the two-term fp16 split runs 3 MFMA products per useful one, DESIGN.md section 3)."""
     useful = BATCH * 1.454e12 * N_FRAMES / 215
     ach = useful / (codec_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 1), "issued": round(3 * ach, 1), "peak": 2500.0, "unit": "TFLOP/s",

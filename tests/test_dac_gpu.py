@@ -349,7 +349,7 @@ def test_bf16_module_mode_of_the_text2semantic_cli_vs_oracle_in_the_same_mode(fu
     noise, e_hip, e_x = rms(want16, want32), rms(got, want32), rms(got, want16)
     print(f"bf16 module: signal rms {sig:.4f}; vs exact fp32: oracle {noise:.2e}, HIP {e_hip:.2e}; HIP vs bf16 oracle {e_x:.2e}")
     assert noise > 1e-5 and e_hip <= 1.5 * noise + 1e-5 and e_x <= 2.0 * noise + 1e-5
-    # encode in this mode: bf16 parameters and bf16 audio, fp32 activations (the reference's own bf16
+    # encode in this mode: bf16 parameters and bf16 audio, fp32 activations (docs/design_history.md section 5.8: the reference's own bf16
     # encode agrees with its fp32 codes in ~1 index of 6 on synthetic weights, so index parity is undefined upstream)
     n = cfg.frame_length * 3
     audio = 0.2 * torch.randn(1, 1, n, generator=torch.Generator().manual_seed(5))
