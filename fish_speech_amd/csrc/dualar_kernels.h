@@ -68,6 +68,12 @@ struct LinearArgs {
   // addmm; skinny kernel, EPI_STORE only
   const bf16_t* bias;
   int late_epi;            // A/B measurements only (FMI_GEMV_LATE_EPI): epilogue operands loaded after the last barrier
+  // tools/gemv_ksplit_probe.hip only (linear_skinny_kernel<..., KSL > 1>: the K range split over gridDim.y work-groups
+  // per row block -- fewer activation requests per weight byte -- with a fixed-order cross-work-group reduction):
+  float* part;             // [gridDim.y][gridDim.x][TILES][256] fp32 partial sums
+  unsigned* cnt;           // [gridDim.x] arrival counters (zero between launches); nullptr = partials only (upper bound)
+  int part_proto;          // 0: partials by plain stores + agent-scope release / acquire fences; 1: partials by agent-scope
+                           //    (write-through / L2-bypassing) relaxed atomic stores and loads, no cache-wide fence
 };
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s);  // M <= 16
 

@@ -405,8 +405,12 @@ constexpr int SKINNY_XH = 5;   // k-tile pairs of activations a wave can hold (K
 //
 // Epilogue operands that do not depend on the products (residual, int8 row scale, bias) are requested at the top of the
 // kernel: loaded after the last barrier they were one more dependent L2 miss at the tail of every wo / w2 launch.
-template <int WAVES, int EPI, bool NORM, int UNR, int TILES, int XR, bool NT = true, bool Q8 = false, int ROWS = 16, int XH = 0>
+// KSL > 1 (tools/gemv_ksplit_probe.hip only, never launched by the library): gridDim.y = KSL work-groups share a row block,
+// each over 1 / KSL of the k-tile pairs; partial sums meet in a.part, the last arriver (a.cnt) adds them in slice order and
+// runs the epilogue.
+template <int WAVES, int EPI, bool NORM, int UNR, int TILES, int XR, bool NT = true, bool Q8 = false, int ROWS = 16, int XH = 0, int KSL = 1>
 __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR == 1) ? ((XR == 8 || XH == 0) ? 6 : 4) : 1) void linear_skinny_kernel(LinearArgs a) {
+  static_assert(KSL == 1 || (!NORM && !Q8 && XR == 8), "k-slices: plain bf16 linears of up to 8 rows");
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
   static_assert(XR == 8 || XR == 16, "activation row sets of 8");
   static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || (!Q8 && EPI != EPI_SILU)), "row-balanced tiles: bf16, no SwiGLU");
@@ -425,7 +429,9 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
   const int KT = a.K >> 5, P = KT >> 1;
   const int tile0 = blockIdx.x * TILES;
 
-  const int pbeg = (int)((int64_t)wave * P / WAVES), pend = (int)((int64_t)(wave + 1) * P / WAVES);
+  const int Psl = KSL > 1 ? P / KSL : P;                 // pairs of this work-group's k-slice
+  const int pz0 = KSL > 1 ? (int)blockIdx.y * Psl : 0;
+  const int pbeg = pz0 + (int)((int64_t)wave * Psl / WAVES), pend = pz0 + (int)((int64_t)(wave + 1) * Psl / WAVES);
   // weight addressing: a wave-uniform 64-bit base per (tile, k-tile) + one 32-bit per-lane byte offset (SGPR base +
   // VGPR offset loads: per-lane 64-bit pointers cost the norm-fused w1|w3 variant its third work-group per CU).
   // bf16: [tile][KT][TSTRIDE] u32x4; int8: [tile][P][64] u32x4 (a pair per entry)
@@ -746,6 +752,55 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
 #pragma unroll
   for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[0][t];
   __syncthreads();
+
+  if constexpr (KSL > 1) {
+    // this slice's sums (wave order, as below) -> a.part; with a.cnt the last of the KSL arrivals of the row block adds the
+    // slices in slice order -- the same bits whichever work-group happens to arrive last -- and goes on to the epilogue
+    __shared__ int s_last;
+    float* mine = a.part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TILES * 256);
+    if (tid < 256) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sacc += red[w][t][tid];
+        if (a.part_proto == 1) __hip_atomic_store(reinterpret_cast<unsigned*>(mine) + t * 256 + tid, __float_as_uint(sacc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else mine[t * 256 + tid] = sacc;
+      }
+    }
+    if (a.cnt == nullptr) return;
+    if (a.part_proto == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores are acknowledged
+    else __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = a.part_proto == 1 ? __hip_atomic_fetch_add(&a.cnt[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                              : __hip_atomic_fetch_add(&a.cnt[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = prev == (unsigned)(KSL - 1);
+      if (s_last) a.cnt[blockIdx.x] = 0u;   // (ready for the next launch: stream order separates launches)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (a.part_proto != 1) __threadfence();
+    if (tid < 256) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        float pz[KSL];
+#pragma unroll
+        for (int z = 0; z < KSL; ++z) {
+          const float* src = a.part + ((int64_t)z * gridDim.x + blockIdx.x) * (TILES * 256) + t * 256 + tid;
+          pz[z] = a.part_proto == 1 ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                    : __builtin_nontemporal_load(src);
+        }
+        float sacc = 0.f;
+#pragma unroll
+        for (int z = 0; z < KSL; ++z) sacc += pz[z];
+        red[0][t][tid] = sacc;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) red[w][t][tid] = 0.f;
+      }
+    }
+    __syncthreads();
+  }
 
   if (e_on) {
     const int bb = e_bb, r = e_r;  // consecutive threads -> consecutive output columns
