@@ -7,9 +7,9 @@ names, arguments, cache keys, validation and error types; NOT mirrored -- a stat
 mirrored" -- are the three reference-library management methods upstream's class also defines
 (`list_reference_ids`, `add_reference`, `delete_reference`, reference_loader.py:155-260: directory listing / copy /
 delete behind the HTTP server's routes, control plane per SURVEY.md 8).  What else differs is audio I/O:
-torchaudio is not in this image, so `load_audio` reads wav bytes / files with scipy and resamples with a polyphase
-filter (host plumbing outside the hot path; mp3 / flac / ... references raise a clear error instead of being
-mis-decoded).  `engine.StreamingTTSEngine` inherits both, like `TTSInferenceEngine` does."""
+torchaudio is not in this image, so `load_audio` reads WAV (scipy) and AIFF PCM (standard library) bytes / files and
+resamples with a polyphase filter (host plumbing outside the hot path; mp3 / flac / ... references raise a clear error
+instead of being mis-decoded).  `engine.StreamingTTSEngine` inherits both, like `TTSInferenceEngine` does."""
 from __future__ import annotations
 
 import io
@@ -48,6 +48,38 @@ def read_ref_text(ref_text):
     if path.exists() and path.is_file():
         return path.read_text(encoding="utf-8")
     return ref_text
+
+
+def _read_aiff(src):
+    """AIFF / AIFF-C with uncompressed big-endian PCM through the standard library (reference_loader.py:133-141 accepts any
+    container torchaudio decodes; AUDIO_EXTENSIONS lists .aiff / .aif / .aifc).  -> (sample_rate, int array (frames[, ch]))
+    or None if `src` is not such a file."""
+    import warnings
+
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)
+            import aifc
+        if hasattr(src, "seek"):
+            src.seek(0)
+        with aifc.open(src, "rb") as f:
+            if f.getcomptype() not in (b"NONE", b"sowt"):
+                return None
+            nch, width, sr, n = f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()
+            raw = f.readframes(n)
+            little = f.getcomptype() == b"sowt"
+    except Exception:  # noqa: BLE001 -- not an AIFF file (or a flavour aifc cannot read)
+        return None
+    if width == 3:      # 24-bit: widen to int32 (value << 8), so that the integer scaling below applies
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3)
+        b = b[:, ::-1] if not little else b
+        data = ((b[:, 0].astype(np.int32) | (b[:, 1].astype(np.int32) << 8) | (b[:, 2].astype(np.int8).astype(np.int32) << 16)) << 8)
+    elif width in (1, 2, 4):
+        dt = np.dtype({1: "i1", 2: "i2", 4: "i4"}[width]).newbyteorder("<" if little else ">")
+        data = np.frombuffer(raw, dtype=dt).astype({1: np.int8, 2: np.int16, 4: np.int32}[width])
+    else:
+        return None
+    return int(sr), (data.reshape(-1, nch) if nch > 1 else data)
 
 
 class VQManager:
@@ -126,10 +158,13 @@ class ReferenceLoader:
         try:
             original_sr, data = wavfile.read(src)
         except ValueError as e:
-            raise ValueError("only RIFF/WAVE reference audio can be decoded without torchaudio "
-                             f"(scipy.io.wavfile: {e})") from e
+            aiff = _read_aiff(src)          # the one other container the standard library decodes (.aiff / .aif / .aifc PCM)
+            if aiff is None:
+                raise ValueError("only RIFF/WAVE and AIFF (PCM) reference audio can be decoded without torchaudio "
+                                 f"(scipy.io.wavfile: {e})") from e
+            original_sr, data = aiff
         x = data.astype(np.float32)
-        if data.dtype == np.uint8:           # 8-bit PCM is unsigned: (x - 128) / 128, as torchaudio / soundfile decode it
+        if data.dtype == np.uint8:           # 8-bit WAV PCM is unsigned: (x - 128) / 128, as torchaudio / soundfile decode it
             x = (x - 128.0) / 128.0
         elif np.issubdtype(data.dtype, np.integer):
             x /= float(2 ** (8 * data.dtype.itemsize - 1))   # 1 / 32768 for int16, not 1 / iinfo.max

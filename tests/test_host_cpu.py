@@ -317,6 +317,24 @@ def test_reference_loader_and_vq_manager_mirror_the_reference_semantics(tmp_path
     b8 = io.BytesIO()
     wavfile.write(b8, sr, np.array([0, 64, 128, 192, 255], dtype=np.uint8))
     assert np.array_equal(eng.load_audio(b8.getvalue(), sr), np.array([-1.0, -0.5, 0.0, 0.5, 127 / 128], dtype=np.float32))
+    # AIFF PCM (round 5; `.aiff / .aif / .aifc` are in AUDIO_EXTENSIONS upstream, torchaudio decodes them there): big-endian
+    # 16-bit mono from bytes, 24-bit stereo from a file path (down-mixed), same scaling as the WAV path
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        import aifc
+    p16 = tmp_path / "mono16.aif"
+    with aifc.open(str(p16), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+        f.writeframes(np.array([-32768, -16384, 0, 16384, 32767], dtype=">i2").tobytes())
+    assert np.array_equal(eng.load_audio(p16.read_bytes(), sr), np.array([-1.0, -0.5, 0.0, 0.5, 32767 / 32768], dtype=np.float32))
+    p24 = tmp_path / "stereo24.aiff"
+    with aifc.open(str(p24), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(3); f.setframerate(sr)
+        vals = [(-8388608, -8388608), (4194304, 0), (0, -4194304)]
+        f.writeframes(b"".join(int(v).to_bytes(3, "big", signed=True) for pair in vals for v in pair))
+    assert np.array_equal(eng.load_audio(str(p24), sr), np.array([-1.0, 0.25, -0.25], dtype=np.float32))
 
 
 def test_generate_stream_argument_errors():
