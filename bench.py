@@ -343,7 +343,7 @@ def prefill_roofline(cfg, prefill_ms):
     flops = 2.0 * cfg.n_layer * per_layer * rows + BATCH * cfg.n_layer * 4.0 * cfg.n_head * cfg.head_dim * PROMPT_T * PROMPT_T / 2
     ach = flops / (prefill_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-            "kernel": "prefill: linear_tiled_ws_kernel<0|1|2> + attn_prefill_mfma_kernel over 8 x 200 rows, 36 layers "
+            "kernel": "prefill: linear_tiled_256p_kernel<0|1|2, MF> + attn_prefill_mfma_kernel over 8 x 200 rows, 36 layers "
                       "(time includes the first frame's head + fast-AR chain)",
             "flops_per_launch": flops, "avg_launch_ms": round(prefill_ms, 3), "traffic": None}
 

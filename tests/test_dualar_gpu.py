@@ -361,6 +361,21 @@ def test_teacher_forced_taps_and_equal_draws_on_the_sampled_fixture():
     assert st["frames"] == n and st["exact"] == st["decisions"] == n * cfg.num_codebooks, st
 
 
+def test_stream_priority_change_recreates_the_stream_and_leaves_generation_unchanged():
+    """fmi_dualar_set_stream_priority (round 5): the handle's private stream is re-created with another dispatch priority,
+    the captured frame graphs are dropped -- a scheduling knob, the tokens do not move."""
+    from fish_speech_amd.dual_ar import generate
+
+    cfg, state, z = load_dualar_case("tiny_peaky")
+    model = _make_model(cfg, state)
+    kw = dict(prompt=torch.from_numpy(z["prompt"]), max_new_tokens=int(z["max_new"]), temperature=float(z["temperature"]),
+              top_p=float(z["top_p"]), top_k=int(z["top_k"]), seed=int(z["uniform_seed"]))
+    want = z["tokens"]
+    for prio in (-1, 1, 0):
+        model.set_stream_priority(prio)
+        assert np.array_equal(generate(model=model, **kw).numpy(), want), prio
+
+
 def test_generate_matches_oracle_run_on_this_box():
     """Same comparison against the oracle run on the GPU box's own CPU (tiny case, greedy)."""
     from fish_speech_amd.dual_ar import generate
