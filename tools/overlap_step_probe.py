@@ -72,9 +72,15 @@ def main():
               f"{sum(fms[1:]) / max(1, len(fms) - 1):.4f})  {audio / dt:6.2f} audio-s/s", flush=True)
         return wav
 
+    modes = sys.argv[2] if len(sys.argv) > 2 else "plain,prio,mask,floor"
+    if modes == "only-serial":      # (for a kernel trace of one regime alone: tools/r05_overlap_trace.sh)
+        serial("serial (bench.py r04)")
+        return
+    if modes == "only-overlapped":
+        overlapped("overlapped, plain streams")
+        return
     codes = serial("serial (bench.py r04)")
     want = codec.from_indices(codes.clone())
-    modes = sys.argv[2] if len(sys.argv) > 2 else "plain,prio,mask,floor"
     if "plain" in modes:
         wav = overlapped("overlapped, plain streams")
         assert torch.equal(wav, want), "the overlapped step's waveform differs from the serial step's"
