@@ -204,6 +204,40 @@ def test_sampler_bit_exact_vs_oracle(lib, top_k, n):
             assert int(got[b]) == want, (b, int(got[b]), want)
 
 
+@pytest.mark.parametrize("top_k", [1, 30, 64])
+def test_sampler_candidate_selection_paths_bit_exact_on_adversarial_rows(lib, top_k):
+    """Round 5: the top-k candidates are found by counting keys per distance below the row maximum (32 buckets of 16 bf16
+    key units) -- one shared list when at most 64 keys lie inside the reach that holds k, per-wave lists when more do, the
+    radix descent per wave when a wave alone holds more than 64 or the reach (four octaves) does not hold k.  Rows built
+    to hit each path and each boundary, against the oracle's draw: a lone peak over noise far below (descent), all
+    logits equal (4097-way tie: descent, ties by index), exactly k / k + 1 / 64 / 65 / 300 keys inside one bucket of the
+    maximum, every logit negative, a maximum at the top of the bf16 range of interest, -inf entries, and n not a
+    multiple of the work-group size."""
+    g = torch.Generator().manual_seed(1000 + top_k)
+    n, vocab = 4097, 4300
+    ids = torch.sort(torch.randperm(vocab, generator=g)[:n]).values.int()
+    rows = []
+    base = torch.randn(n, generator=g) * 0.5 - 20.0                      # noise far below everything that follows
+    r = base.clone(); r[123] = 30.0; rows.append(r)                      # lone peak: the reach never holds k > 1
+    rows.append(torch.full((n,), 1.5))                                   # every key equal
+    for m in (top_k, top_k + 1, 64, 65, 300):                            # m keys within a few steps of the maximum
+        r = base.clone()
+        idx = torch.randperm(n, generator=g)[:m]
+        r[idx] = 8.0 - 0.03125 * torch.randint(0, 12, (m,), generator=g).float()
+        rows.append(r)
+    rows.append(-(torch.rand(n, generator=g) * 3 + 0.5))                 # all negative, dense near the maximum
+    r = torch.randn(n, generator=g) * 40.0; rows.append(r)               # wide: the k-th largest is octaves below the max
+    r = torch.randn(n, generator=g); r[::3] = float("-inf"); rows.append(r)
+    logits = torch.stack(rows).bfloat16()
+    for nn in (n, 4000, 2049):
+        lg = logits[:, :nn].contiguous()
+        idn = ids[:nn].contiguous()
+        got = _sample(lib, lg, idn, (0.7, 0.9, top_k, 4321, 0), 9, 1, None, (0, 0))
+        for b in range(lg.shape[0]):
+            want = _oracle_draw(lg[b], idn, vocab, 0.7, 0.9, top_k, 4321, 0, 9, 1)
+            assert int(got[b]) == want, (nn, b, int(got[b]), want)
+
+
 def test_sampler_log_table_matches_torch_bf16():
     """-log(u) for the 256 possible uniforms, in bf16, equals torch's CPU result (inference.py:44-45);
     checked through single-candidate draws: u == 0 is the only case returning token 0."""
