@@ -453,6 +453,8 @@ class MiDAC:
             raise ValueError(f"expected {self.config.n_codebooks + 1} codebooks, got {nb}")
         out = torch.empty(B, 1, T * self.frame_length, dtype=torch.float32, device=self.device)
         self._decode_call(self.lib.fmi_dac_decode, C.c_void_p(work.data_ptr()), B, T, C.c_void_p(out.data_ptr()), self._stream())
+        if self._async and (work is not indices or self.module_dtype != torch.float32):
+            self.wait_stream()     # the copy-back / dtype conversion below run on torch's stream: order it after the decode
         if work is not indices:
             try:
                 indices.copy_(work)  # the reference mutates its argument; keep that visible to the caller
