@@ -603,13 +603,20 @@ def run_config5_staggered(model, codec, cfg, n_req=16, gap_s=0.25):
             "audio_sec_per_s": round(samples / SAMPLE_RATE / wall, 2), "wall_s": round(wall, 3)}
 
 
+# FMI_BENCH_ONE_GPU=1: a DEBUG mode for boxes with one GPU -- every rank of `--gpus N` uses cuda:0 and the process group is
+# gloo (RCCL refuses two ranks on one device; gloo carries device tensors).  It executes bench.py's own N > 1 path end to
+# end -- the re-exec under torch.distributed.run, per-rank construction, both arena broadcasts, the barriers, the MAX / SUM
+# reductions, rank 0's JSON line -- with the ranks time-slicing one GPU, so its numbers are NOT a result (the line says so).
+ONE_GPU_DEBUG = os.environ.get("FMI_BENCH_ONE_GPU", "0") not in ("", "0")
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     import socket
     import subprocess
 
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not ONE_GPU_DEBUG:
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node -- refusing to report a "
                          f"{n}-GPU number from fewer devices")
     with socket.socket() as sk:
@@ -618,6 +625,8 @@ def respawn_under_torchrun(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if ONE_GPU_DEBUG:
+        env.setdefault("GLOO_SOCKET_IFNAME", "lo")
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
@@ -646,7 +655,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device("cuda:0" if ONE_GPU_DEBUG else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     dist = None
     if world > 1 or args.force_dist:
@@ -659,7 +668,10 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        if ONE_GPU_DEBUG:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     # the library ships prebuilt in-tree; if it is stale only one process per node compiles it
     from fish_speech_amd.build import build
@@ -733,7 +745,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16 activations, int8 weights (NOT the headline configuration)" if args.int8 else "bf16",
-        "data": "synthetic (random-init S2-Pro-shaped weights, random 200-token prompts, EOS ignored, 215 frames)",
+        "data": ("INVALID AS A RESULT (FMI_BENCH_ONE_GPU debug mode: every rank on cuda:0 over gloo) -- " if ONE_GPU_DEBUG else "")
+                + "synthetic (random-init S2-Pro-shaped weights, random 200-token prompts, EOS ignored, 215 frames)",
         "config": {"workload": "configs[2]: S2-Pro 4B batch=8, 200-token prompts -> 10 s audio, hipGraph inner-AR loop",
                    "batch_per_gpu": BATCH, "prompt_tokens": PROMPT_T, "frames": N_FRAMES, "parallelism": f"utterance-sharded x{world}",
                    "codec_in_step": codec is not None},

@@ -198,3 +198,28 @@ def test_two_processes_on_one_gpu_under_torch_distributed():
     if "GLOO_CUDA_UNSUPPORTED" in out:
         pytest.skip("this torch build's gloo cannot broadcast device tensors")
     assert r.returncode == 0 and "WORLD2_GPU_OK" in out, out[-6000:]
+
+
+def test_bench_py_runs_its_own_two_rank_path_on_one_gpu():
+    """bench.py --gpus 2 end to end in its one-GPU debug mode (FMI_BENCH_ONE_GPU=1: both ranks on cuda:0, gloo instead of
+    RCCL): the re-exec under torch.distributed.run, rank 1's construction through dist.broadcast_arena (no tensor ever
+    loaded there), the barriers around the timed region, the MAX reduction of the elapsed time and rank 0's ONE JSON
+    line with n_gpus = 2 and twice the audio of a one-rank step.  The ranks time-slice the GPU, so the line marks itself
+    invalid as a result; what is checked is that the N > 1 code of the benchmark runs and accounts correctly."""
+    import json
+
+    env = dict(os.environ, FMI_BENCH_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=400)
+    out = r.stdout.decode(errors="replace")
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, out[-4000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["data"].startswith("INVALID AS A RESULT")
+    assert d["config"]["parallelism"] == "utterance-sharded x2" and d["config"]["batch_per_gpu"] == 8
+    audio = 2 * 8 * 215 * 2048 / 44100                       # both ranks' utterances count
+    assert abs(d["value"] - audio / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert d["breakdown_ms"]["launches_per_frame"] == 374 and 0 < d["roofline"]["frac"] < 1
