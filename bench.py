@@ -691,6 +691,14 @@ def main():
         replicate = lambda m: broadcast_arena(m, src=0)   # noqa: E731
     model, codec, state, codec_state = construct(cfg, device, rank, int8=args.int8, with_codec=not args.no_codec,
                                                  replicate=replicate)
+    if ONE_GPU_DEBUG and dist:   # debug mode only: did every rank receive rank 0's arenas?  (sum of the bytes as int64 words)
+        sums = [int(o.arena[: o.arena.numel() // 8 * 8].view(torch.int64).sum().item()) for o in (model, codec) if o is not None]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, sums)
+        if any(g != gathered[0] for g in gathered):
+            raise SystemExit(f"rank {rank}: arena checksums differ across ranks after the broadcast: {gathered}")
+        if rank == 0:
+            print(f"[one-GPU debug] arena checksums equal on all {world} ranks: {gathered[0]}", file=sys.stderr, flush=True)
     if args.no_graph:
         model.set_graph(False)
     prompts = make_prompts(cfg, BATCH, 1000 + rank * BATCH)
