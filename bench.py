@@ -706,9 +706,15 @@ def main():
     prompts = make_prompts(cfg, BATCH, 1000 + rank * BATCH)
     seeds = [4242 + rank * BATCH + i for i in range(BATCH)]
 
+    def stage(what):   # (debug mode only: where a rank was, should it die)
+        if ONE_GPU_DEBUG:
+            print(f"[one-GPU debug] rank {rank}: {what}", file=sys.stderr, flush=True)
+
+    stage("constructed")
     for _ in range(args.warmup):
         run_step(model, codec, prompts, seeds, device)
     torch.cuda.synchronize()
+    stage("warm-up done")
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
