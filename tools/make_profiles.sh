@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r03}
 shift || true
-SECTIONS=${*:-step codec prefill pmc attn stream gemm}      # optional: only these sections
+SECTIONS=${*:-step codec prefill pmc attn stream gemm}      # optional: only these sections (+ "probes", round 5)
 want() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
@@ -72,5 +72,14 @@ want stream && python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt"
 # prefill GEMM variants per shape (tools/gemm_bench.hip; the binary is built on the authoring side: see the file's header)
 if want gemm && [ -x tools/bin/gemm_bench ]; then
 { echo "# tools/bin/gemm_bench wxptsu on MI355X (libfishmi.so sha1 $SHA, tree $HEAD): w = wave-specialised 128x128 (round 3), x = 128x256 three-stage tile (round 3), p / u / s / t = linear_tiled_256p_kernel with 256 / 192 / 128 / 64-row tiles (round 4: what launch_linear_tiled chooses among); every variant checked bit for bit against the 4-wave LDS-staged kernel"; tools/bin/gemm_bench wxptsu; } > "$OUT/${TAG}_gemm_bench.txt" 2>&1
+fi
+# round-5 probes (binaries from tools/build_tools.sh; each prints its own reading): sampler stages, the K-slice GEMV
+# decomposition, Infinity-Cache residency, prefetch from the previous kernel; the overlapped step against the serial one
+if want probes; then
+  [ -x tools/bin/sampler_bench ] && { echo "== bucket counts (default)"; tools/bin/sampler_bench; echo "== FMI_SAMPLE_DESCENT=1"; FMI_SAMPLE_DESCENT=1 tools/bin/sampler_bench; } > "$OUT/${TAG}_sampler_stages.txt" 2>&1
+  [ -x tools/bin/gemv_ksplit_probe ] && tools/bin/gemv_ksplit_probe > "$OUT/${TAG}_gemv_ksplit_probe.txt" 2>&1
+  [ -x tools/bin/mall_resident_probe ] && tools/bin/mall_resident_probe > "$OUT/${TAG}_mall_resident_probe.txt" 2>&1
+  [ -x tools/bin/l2_prefetch_probe ] && tools/bin/l2_prefetch_probe > "$OUT/${TAG}_l2_prefetch_probe.txt" 2>&1
+  python tools/overlap_step_probe.py 4 plain,prio,floor > "$OUT/${TAG}_overlap_step.txt" 2>&1
 fi
 ls -la "$OUT"
