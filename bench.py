@@ -271,7 +271,9 @@ def cpu_baseline(cfg, state_dev, codec_state_dev, n_frames=64, codec_frames=N_FR
     per_frame = max(t_all - t_prefill, 1e-9) / n_frames
     pf_a = max(t_half - t_prefill, 1e-9) / half                  # frames [0, half): mean context PROMPT_T + half / 2
     pf_b = max(t_all - t_half, 1e-9) / (n_frames - half)         # frames [half, n): mean context PROMPT_T + 3 half / 2
-    slope = (pf_b - pf_a) / half                                  # seconds per frame per frame of context
+    # seconds per frame per frame of context.  A frame cannot get cheaper with a longer context: a negative measured slope
+    # is timer / scheduler noise between the two halves (seen: 0.262 then 0.227 s/frame) and is read as zero, i.e. flat
+    slope = max((pf_b - pf_a) / half, 0.0)
     t_flat = t_prefill + (N_FRAMES - 1) * per_frame
     t_ar = t_prefill + sum(max(pf_a + slope * (i - half / 2), 0.0) for i in range(N_FRAMES - 1))
     del orc, st
