@@ -170,8 +170,7 @@ def construct(cfg, device, rank, int8=False, with_codec=True, replicate=None):
         state = synthetic_state_on_device(cfg, device)
         model.load_state_dict(quantize_state_int8_on_device(state) if int8 else state)
     if replicate is not None:
-        replicate(model)
-        torch.cuda.synchronize(device)   # (start-up, untimed: the arena is complete before anything derives from it)
+        replicate(model)   # (dist.broadcast_arena orders the model's stream after the collective: no host sync here)
     # 1024 positions per slot: covers config 3's 400 + 430.  Sixteen slots (the handle's caches are set up once): the timed
     # region runs 8 utterances in 8 of them, other_configs.batch16 all sixteen
     model.setup_caches(2 * BATCH, cfg.max_seq_len)
@@ -187,7 +186,6 @@ def construct(cfg, device, rank, int8=False, with_codec=True, replicate=None):
             codec.load_folded_state(codec_state)
         if replicate is not None:
             replicate(codec)
-            torch.cuda.synchronize(device)
     return model, codec, state, codec_state
 
 

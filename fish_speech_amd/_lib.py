@@ -53,7 +53,7 @@ _SIGS = {
     "fmi_dualar_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int64, _I, _P]),
     "fmi_dualar_load_tensor_int8": (C.c_int, [_P, C.c_char_p, _P, _P, C.c_int64, C.c_int64, _I, _P]),
     "fmi_dualar_finalize_weights": (C.c_int, [_P, _P]),
-    "fmi_dualar_weights_ready": (C.c_int, [_P]),
+    "fmi_dualar_weights_ready": (C.c_int, [_P, _P]),
     "fmi_dualar_setup_caches": (C.c_int, [_P, _I, _I]),
     "fmi_dualar_prefill": (C.c_int, [_P, _I, C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.POINTER(SamplingC), _P]),
@@ -74,6 +74,7 @@ _SIGS = {
     "fmi_dualar_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_P),
                                         C.POINTER(_P), C.POINTER(_P)]),
     "fmi_dualar_set_trace": (C.c_int, [_P, _I, C.POINTER(_P)]),
+    "fmi_dualar_fast_chain_forced": (C.c_int, [_P, _I, C.POINTER(C.c_int32), _P, _P, _I, _P, _P]),
     "fmi_dualar_set_graph": (C.c_int, [_P, _I]),
     "fmi_dualar_set_attn_impl": (C.c_int, [_P, _I]),
     "fmi_dualar_set_fast_merge": (C.c_int, [_P, _I]),
@@ -89,7 +90,7 @@ _SIGS = {
     "fmi_dac_destroy": (None, [_P]),
     "fmi_dac_load_tensor": (C.c_int, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64), _I, _P]),
     "fmi_dac_finalize_weights": (C.c_int, [_P, _P]),
-    "fmi_dac_weights_ready": (C.c_int, [_P]),
+    "fmi_dac_weights_ready": (C.c_int, [_P, _P]),
     "fmi_dac_set_precision": (C.c_int, [_P, _I]),
     "fmi_dac_set_async": (C.c_int, [_P, _I]),
     "fmi_dac_set_background": (C.c_int, [_P, _I]),

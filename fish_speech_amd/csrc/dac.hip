@@ -988,8 +988,11 @@ int fmi_dac_set_stream_options(fmi_dac* h, int priority, int cu_mask_words, cons
   return FMI_OK;
 }
 
-int fmi_dac_weights_ready(fmi_dac* h) {
+// as fmi_dualar_weights_ready: the handle's private stream waits for whatever filled the arena on `stream`
+int fmi_dac_weights_ready(fmi_dac* h, void* stream) {
   FMI_REQUIRE(h, "null handle");
+  std::unique_lock<std::mutex> lock_(h->mu);
+  FMI_CHECK(sync_in(h, stream));
   h->ready = true;
   return FMI_OK;
 }

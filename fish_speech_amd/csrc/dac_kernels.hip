@@ -1600,7 +1600,11 @@ int read_clear_f16_overflow(int* dev_word, int* flag, hipStream_t s) {
   int v = 0;
   FMI_CHECK_HIP(hipStreamSynchronize(s));
   FMI_CHECK_HIP(hipMemcpy(&v, dev_word, sizeof(int), hipMemcpyDeviceToHost));
-  if (v) FMI_CHECK_HIP(hipMemset(dev_word, 0, sizeof(int)));
+  if (v) {   // cleared ON the handle's stream and waited for: h->stream is non-blocking, a null-stream memset would
+             // not be ordered before the next launch on it and could wipe (or lose) a freshly raised flag
+    FMI_CHECK_HIP(hipMemsetAsync(dev_word, 0, sizeof(int), s));
+    FMI_CHECK_HIP(hipStreamSynchronize(s));
+  }
   *flag = v;
   return FMI_OK;
 }

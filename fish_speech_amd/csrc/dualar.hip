@@ -87,7 +87,11 @@ struct fmi_dualar {
   bool qkv0_tried = false;
   bool rows_tried = false;             // row-balanced decode copies (LayerW::r_*) derived
   std::vector<void*> row_copies;       // their allocations
-  bool trace = false, use_graph = true, ignore_eos = false;
+  bool use_graph = true, ignore_eos = false;
+  int trace = 0;   // fmi_dualar_set_trace: 0 off, 1 per-position fast logits kept + plain GEMV path, 2 kept on the frame loop's own path (table)
+  bool skinny32 = false;             // linear(): rows 17-32 may take the decode GEMV (set by tail() around the merged fast pass)
+  const int32_t* forced = nullptr;   // fmi_dualar_fast_chain_forced only: the frame that replaces the draws
+  bool tail_in_normed = false;       //   "  : tail()'s input rows are already normed (the hidden the reference hands over)
   bool force_tiled = false;
   int attn_impl = 1;   // prefill attention: 1 = MFMA flash kernel with LDS-staged K/V tiles, 0 = VALU kernel (A/B parity)
   // decode attention: rows at or beyond this position run on the MFMA kernel + merge (launch_attn_decode_long), the
@@ -312,7 +316,9 @@ int linear(fmi_dualar* h, const bf16_t* x, int ldx, const bf16_t* wp, const bf16
   }
   // h->force_tiled: the few suffix rows of a resumed prefill must go through the kernel a full prefill of the
   // whole prompt would have used for them (the tiled GEMM: a row's bits do not depend on how many rows run along)
-  if (M <= 16 && !h->force_tiled) {
+  // (17-32 rows take the decode GEMV only inside tail(): the merged fast positions 0/1 of a batch of 9-16.  Everywhere
+  // else the 16-row boundary between the GEMV and the tiled GEMM stays where dual_ar.py's prefix reuse expects it.)
+  if ((M <= 16 || (M <= 32 && h->skinny32)) && !h->force_tiled) {
     h->launches += 1;
     return launch_linear_skinny(a, s);
   }
@@ -410,7 +416,12 @@ int tail_head(fmi_dualar* h, const bf16_t* xl, int B, hipStream_t s, bf16_t* hf_
   const fmi_dualar_config& c = h->cfg;
   const int dim = c.dim;
   // hn = normed hidden (head input, parity tap); hf = its copy that fast step 0 transforms in place
-  FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s, hf_out ? hf_out : h->hf));
+  if (h->tail_in_normed) {   // test seam: xl IS the normed hidden (what forward_generate returns, llama.py:459-461)
+    FMI_CHECK_HIP(hipMemcpyAsync(h->hn, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
+    FMI_CHECK_HIP(hipMemcpyAsync(hf_out ? hf_out : h->hf, xl, (size_t)B * dim * 2, hipMemcpyDeviceToDevice, s));
+  } else {
+    FMI_CHECK(launch_rmsnorm_rows(xl, dim, h->norm, c.norm_eps, h->hn, dim, B, dim, s, hf_out ? hf_out : h->hf));
+  }
   h->launches += 1;
   return linear(h, h->hn, dim, h->head_live, nullptr, nullptr, 0, h->logits, h->n_live_pad, B, h->n_live_pad, dim,
                 EPI_STORE, s);
@@ -429,8 +440,13 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   // positions 0 and 1 of the fast transformer in one pass over its weights (block_fast: merge01): 2 B <= 16 rows of
   // the decode GEMV; a row's bits do not depend on the rows it travels with, so nothing changes but the traffic
   // (-0.6 GB per frame at the S2 shape) and the launch count (-16)
-  const bool merge = h->merge01 && !h->fpi_w && !c.weight_int8 && 2 * B <= 16 && c.num_codebooks >= 2 && c.fast_dim == c.dim &&
+  const bool merge = h->merge01 && !h->fpi_w && !c.weight_int8 && 2 * B <= 32 && c.num_codebooks >= 2 && c.fast_dim == c.dim &&
                      h->ws.rows >= 2 * B;
+  struct Skinny32 {   // the merged pass of a batch of 9-16 runs 18-32 rows through the GEMV's two-column-set form
+    fmi_dualar* h;
+    explicit Skinny32(fmi_dualar* h_, bool on) : h(h_) { h->skinny32 = on; }
+    ~Skinny32() { h->skinny32 = false; }
+  } skinny32_guard(h, merge);
   bf16_t* const x0 = merge ? h->x01 : h->hf;                                   // position-0 rows
   bf16_t* const xf = merge ? h->x01 + (int64_t)B * c.fast_dim : h->xf;         // rows of positions >= 1
   FMI_CHECK(tail_head(h, xl, B, s, x0));
@@ -438,8 +454,8 @@ int tail(fmi_dualar* h, const bf16_t* xl, int B, const int32_t* row_slot, hipStr
   sa.logits = h->logits; sa.B = B; sa.n = h->n_live; sa.ld = h->n_live_pad; sa.ids = h->live_ids;
   sa.row_slot = row_slot; sa.st = h->st; sa.mode = 0; sa.cb = 0; sa.sem_begin = c.semantic_begin_id;
   sa.sem_end = c.semantic_end_id; sa.im_end = h->ignore_eos ? -1 : c.im_end_id; sa.cbs = c.codebook_size; sa.fast_emb = h->fast_emb;
-  sa.xf = xf; sa.fdim = c.fast_dim; sa.small_k = h->max_top_k <= 64;
-  const bool tab = h->qkv0_tab != nullptr && !h->trace;
+  sa.xf = xf; sa.fdim = c.fast_dim; sa.small_k = h->max_top_k <= 64; sa.forced = h->forced;
+  const bool tab = h->qkv0_tab != nullptr && h->trace != 1;
   sa.qkv0_tab = tab ? h->qkv0_tab : nullptr; sa.qkv0_dim = h->fast.qkv;
   // merged pass: the tabulated q|k|v rows of the slow token's codes land where the GEMV would have put them
   sa.qkv0_out = merge ? h->ws.qkv + (int64_t)B * h->fast.qkv : h->qkv0_pre;
@@ -875,8 +891,12 @@ int fmi_dualar_finalize_weights(fmi_dualar* h, void* stream) {
   return sync_out(h, stream);
 }
 
-int fmi_dualar_weights_ready(fmi_dualar* h) {
+// The arena content was put in place by work enqueued on `stream` (a broadcast, a copy).  Everything this handle derives
+// from it -- the first prefill rebuilds the row-balanced copies and the fast layer-0 q|k|v table FROM the arena -- runs
+// on the handle's private non-blocking stream, which nothing else orders after that work: make it wait here.
+int fmi_dualar_weights_ready(fmi_dualar* h, void* stream) {
   FMI_REQUIRE(h, "null handle");
+  FMI_CHECK(sync_in(h, stream));
   h->ready = true;
   return FMI_OK;
 }
@@ -952,7 +972,7 @@ int fmi_dualar_setup_caches(fmi_dualar* h, int max_batch, int max_seq_len) {
     if (!attn_decode_long_supported(s.H, s.KVH, s.D)) h->attn_long_thr = 0;
     if (h->attn_long_thr > 0) FMI_CHECK(dev_alloc(&h->attn_part, attn_decode_long_part_floats(max_batch, s.H, s.D)));
   }
-  return ensure_rows(h, std::max(max_batch, std::min(16, 2 * max_batch)));   // the merged fast pass runs 2 B <= 16 rows
+  return ensure_rows(h, std::max(max_batch, std::min(32, 2 * max_batch)));   // the merged fast pass runs 2 B <= 32 rows
 }
 
 int fmi_dualar_release(fmi_dualar* h, int slot) {
@@ -989,7 +1009,7 @@ static int prefill_impl(fmi_dualar* h, int n, const int32_t* slot_ids, const int
     ~TiledGuard() { h->force_tiled = false; }
   } guard{h};
   h->force_tiled = pos0 != nullptr && any_long;
-  FMI_CHECK(ensure_rows(h, std::max(rows, std::max(h->max_batch, std::min(16, 2 * h->max_batch)))));
+  FMI_CHECK(ensure_rows(h, std::max(rows, std::max(h->max_batch, std::min(32, 2 * h->max_batch)))));
   std::vector<int32_t> row_slot(rows), row_pos(rows), last(n), slots(n);
   std::vector<int4> tiles;
   // rows per query tile of the prefill attention (1 / 2 / 3 column groups per work-group share the staged K/V blocks):
@@ -1292,6 +1312,49 @@ int fmi_dualar_forward_fast(fmi_dualar* h, int slot, const void* hidden_in_dev, 
   return sync_out(h, stream);
 }
 
+// Test seam for the float parity of the fast chain ON THE FRAME LOOP'S PATH: steps 6-8 of
+// decode_one_token_ar (inference.py:148-176) for the B given slots from given NORMED hidden rows, run by tail() exactly
+// as a decode frame runs it -- batch GEMV, merged positions 0/1 when enabled, the tabulated layer-0 q|k|v when
+// table != 0 -- with every draw REPLACED by the forced frame (slow token, then codes 1..ncb-1 feed positions 2..), and
+// every position's logits kept.  Frame bookkeeping runs too: the slots' frame counters advance like after a frame.
+int fmi_dualar_fast_chain_forced(fmi_dualar* h, int B, const int32_t* slot_ids, const void* hidden_normed_dev,
+                                 const int32_t* forced_dev, int table, void* fast_logits_out_dev, void* stream) {
+  FMI_REQUIRE(h && slot_ids && hidden_normed_dev && forced_dev && fast_logits_out_dev, "null argument");
+  FMI_REQUIRE(h->ready, "weights not ready");
+  FMI_REQUIRE(B >= 1 && B <= h->max_batch, "B=%d out of range", B);
+  for (int i = 0; i < B; ++i) FMI_CHECK(check_slot(h, slot_ids[i]));
+  const fmi_dualar_config& c = h->cfg;
+  FMI_CHECK(ensure_rows(h, std::max(2 * B, 16)));
+  FMI_CHECK(sync_in(h, stream));
+  FMI_CHECK(ensure_qkv0_table(h));
+  hipStream_t s = h->stream;
+  h->row_slot_host.clear();
+  FMI_CHECK_HIP(hipMemcpyAsync(h->ws.row_slot, slot_ids, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  // forced frame by SLOT (the samplers index it like the slot state)
+  const int ncb1 = c.num_codebooks + 1;
+  int32_t* forced_by_slot = nullptr;
+  FMI_CHECK(dev_alloc(&forced_by_slot, (int64_t)h->max_batch * ncb1));
+  FMI_CHECK_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < B; ++i)
+    FMI_CHECK_HIP(hipMemcpyAsync(forced_by_slot + (int64_t)slot_ids[i] * ncb1, forced_dev + (int64_t)i * ncb1,
+                                 (size_t)ncb1 * 4, hipMemcpyDeviceToDevice, s));
+  const int saved_trace = h->trace;
+  h->trace = table ? 2 : 1;
+  h->forced = forced_by_slot;
+  h->tail_in_normed = true;
+  const int rc = tail(h, (const bf16_t*)hidden_normed_dev, B, h->ws.row_slot, s);
+  h->trace = saved_trace;
+  h->forced = nullptr;
+  h->tail_in_normed = false;
+  if (rc == FMI_OK)
+    hipMemcpyAsync(fast_logits_out_dev, h->ftrace, (size_t)B * c.num_codebooks * c.codebook_size * 2,
+                   hipMemcpyDeviceToDevice, s);
+  hipStreamSynchronize(s);
+  hipFree(forced_by_slot);
+  FMI_CHECK(rc);
+  return sync_out(h, stream);
+}
+
 // Row-major tables inside the arena that the host mirror may index itself (embedding lookups are
 // tensor plumbing): which = 0 fast_embeddings (codebook_size x fast_dim bf16), 1 live ids (int32 n_live)
 int fmi_dualar_table_ptr(fmi_dualar* h, int which, void** ptr, int* rows, int* cols) {
@@ -1326,11 +1389,12 @@ int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* l
 
 int fmi_dualar_set_trace(fmi_dualar* h, int enable, void** fast_trace) {
   FMI_REQUIRE(h, "null handle");
-  if (h->trace != (enable != 0)) {   // the captured frames embed (or lack) the trace copies and the table's use
+  FMI_REQUIRE(enable >= 0 && enable <= 2, "trace mode %d", enable);
+  if (h->trace != enable) {   // the captured frames embed (or lack) the trace copies and the table's use
     FMI_CHECK_HIP(hipStreamSynchronize(h->stream));
     drop_graphs(h);
   }
-  h->trace = enable != 0;
+  h->trace = enable;
   if (fast_trace) *fast_trace = h->ftrace;
   return FMI_OK;
 }

@@ -182,6 +182,7 @@ struct SampleArgs {
   int32_t* out_tok;       // [B]
   int small_k;            // 1 = every slot uses top_k <= 64 (fast single-wave finish)
   int dbg_stop;           // profiling only: return after stage N of sample_small_kernel (0 = run all)
+  const int32_t* forced;  // test seam (fmi_dualar_fast_chain_forced): [slots][ncb1] frame that REPLACES every draw, or nullptr
   int short_path;         // set by launch_sample: 1 = bucket-count candidate selection (round 5), 0 = radix descent in every wave (FMI_SAMPLE_DESCENT=1; A/B)
 };
 int launch_sample(const SampleArgs& a, hipStream_t s);

@@ -379,10 +379,14 @@ constexpr int SKINNY_XH = 5;   // k-tile pairs of activations a wave can hold (K
 
 // UNR = k-tile pairs in flight per wave; TILES = 16-row weight tiles per work-group (SwiGLU: gate/up tiles
 // alternate, so TILES is even).
-// XR = activation rows per set of all-lanes loads: 8 (M <= 8: one load of eight full cache lines per pair) or 16
-// (M <= 16, round 4: a second load brings rows 8-15; tile 0 / tile 1 of the pair then accumulate rows 8-15 in a second
-// accumulator pair, columns 0-7 / 8-15 again).  A row's products and their order are the same in both forms and the same
-// whichever of the two loads the row arrives in, so its result does not depend on the batch it is in.
+// XR = activation rows the launch can take: 8 (M <= 8: ONE all-lanes load of eight full cache lines is the B operand of
+// both k-tiles of a pair -- rows in columns 0-7 for tile 0, 8-15 for tile 1, half of every product is padding), or 16 / 32
+// (round 6, the NATIVE form: a column set = 16 activation rows in the 16 MFMA columns, one 16-byte load per lane and
+// k-tile, every column of every product is a row's; XR = 32 = two column sets with their own accumulators).  Round 4's
+// 16-row form was two 8-row sets (twice the MFMAs and accumulators of the 8-row form: w1|w3 25.7 us at M = 16 against
+// 20.4 at M = 8); the native form costs what the 8-row form costs.  In every form a row sees the same products in the same
+// order -- k-tile 0 / k-tile 1 of every pair in two accumulators that meet once at the end -- and its RMSNorm statistics
+// the same partition and tree, so its result does not depend on the batch it is in or on the form the row count selects.
 // Q8: the weights are the int8 tiles of a weight-only-int8 checkpoint (a.wq, launch_pack_weight_int8): one 16-byte
 // load per lane brings both k-tiles of a pair, converted to bf16 in registers (exact: |v| <= 128) right before the
 // same MFMAs -- the products, their order and hence the result bits equal the bf16 kernel on the dequantised
@@ -409,18 +413,23 @@ constexpr int SKINNY_XH = 5;   // k-tile pairs of activations a wave can hold (K
 // each over 1 / KSL of the k-tile pairs; partial sums meet in a.part, the last arriver (a.cnt) adds them in slice order and
 // runs the epilogue.
 template <int WAVES, int EPI, bool NORM, int UNR, int TILES, int XR, bool NT = true, bool Q8 = false, int ROWS = 16, int XH = 0, int KSL = 1>
-__global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR == 1) ? ((XR == 8 || XH == 0) ? 6 : 4) : 1) void linear_skinny_kernel(LinearArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR == 1) ? (((XR == 8 || XH == 0) && XR != 32) ? 6 : 4) : 1) void linear_skinny_kernel(LinearArgs a) {
   static_assert(KSL == 1 || (!NORM && !Q8 && XR == 8), "k-slices: plain bf16 linears of up to 8 rows");
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
-  static_assert(XR == 8 || XR == 16, "activation row sets of 8");
+  static_assert(XR == 8 || XR == 16 || XR == 32, "8 rows, or column sets of 16");
+  static_assert(!(Q8 && XR != 8), "int8 tiles: the 8-row form only");
   static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || (!Q8 && EPI != EPI_SILU)), "row-balanced tiles: bf16, no SwiGLU");
   static_assert(XH == 0 || NORM, "held activation fragments belong to the norm-fused variants");
-  constexpr int XS = XR / 8;          // all-lanes activation loads per k-tile pair
+  constexpr bool NAT = XR >= 16;            // native form: 16 activation rows per column set
+  constexpr int CS = NAT ? XR / 16 : 1;     // column sets
+  constexpr int XS = NAT ? 2 * CS : 1;      // activation registers (16-byte loads) per k-tile pair: [2 cs + k-tile] / the one
+  constexpr int NACC = 2 * CS;              // accumulators per weight tile: [2 cs + k-tile of the pair]
+  constexpr int RS = NAT ? 16 : 8;          // rows per set
   constexpr int XHN = XH > 0 ? XH : 1;
   constexpr int TSTRIDE = ROWS * 4;   // u32x4 per (tile, k-tile): ROWS rows x 4 lane groups
-  __shared__ float red[WAVES][TILES][256];
-  __shared__ float s_rstd[16];
-  __shared__ float s_part[WAVES][16];
+  __shared__ float red[WAVES][TILES][CS * 256];
+  __shared__ float s_rstd[32];
+  __shared__ float s_part[WAVES][32];
   __shared__ uint4 s_nw[(XH > 0 ? XH : 0) * WAVES * 8 + 1];   // XH > 0: the norm weight vector (K / 8 chunks of 8)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -442,14 +451,20 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     return reinterpret_cast<const u32x4*>(wbase + unit * 16 + wlane);
   };
 
-  // activation fragment addressing: fetch lane = kt*32 + g'*8 + row -> x[8 s + row][64 p + 32 kt + 8 g' ..] for row
-  // set s; as MFMA B operand that register is column (g'&1)*8 + row, lane group kt*2 + (g'>>1) (see packed_k0)
-  const int f_off = (lane >> 5) * 32 + ((lane >> 3) & 3) * 8;
+  // activation fragment addressing.  8-row form: fetch lane = kt*32 + g'*8 + row -> x[row][64 p + 32 kt + 8 g' ..]; as
+  // MFMA B operand that register is column (g'&1)*8 + row, lane group kt*2 + (g'>>1) (see packed_k0): the "k-tiles" of a
+  // pair are its even / odd 8-element chunks.  Native form, register 2 cs + h: lane (q = lane >> 4, row = lane & 15) ->
+  // x[16 cs + row][64 p + 16 q + 8 h ..] = chunk 2 q + h: column `row`, lane group q of k-tile h -- the same chunk in the
+  // same lane group as in the 8-row form.  k_off = the chunk's element offset inside the pair (norm weights use it too).
   const char* __restrict__ xbase = reinterpret_cast<const char*>(a.x);
-  uint32_t xoff[XS];
+  uint32_t xoff[XS], k_off[XS];
 #pragma unroll
-  for (int s = 0; s < XS; ++s) xoff[s] = (uint32_t)(min(s * 8 + (lane & 7), a.M - 1) * a.ldx + f_off) * 2u;
-  auto xptr = [&](int s, int p) -> const uint4* { return reinterpret_cast<const uint4*>(xbase + (int64_t)p * 128 + xoff[s]); };
+  for (int i = 0; i < XS; ++i) {
+    k_off[i] = NAT ? (uint32_t)((lane >> 4) * 16 + (i & 1) * 8) : (uint32_t)((lane >> 5) * 32 + ((lane >> 3) & 3) * 8);
+    const int row = NAT ? (i >> 1) * 16 + (lane & 15) : (lane & 7);
+    xoff[i] = (uint32_t)(min(row, a.M - 1) * a.ldx + (int)k_off[i]) * 2u;
+  }
+  auto xptr = [&](int i, int p) -> const uint4* { return reinterpret_cast<const uint4*>(xbase + (int64_t)p * 128 + xoff[i]); };
   const char* __restrict__ nbase = reinterpret_cast<const char*>(a.norm_w);
 
   // XH > 0: the norm weight vector (K / 8 = XH * WAVES * 8 <= WAVES * 64 chunks: one per thread) is requested FIRST, so
@@ -495,17 +510,25 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
   }
 
   // epilogue operands (see above); a.late_epi (A/B measurements only) loads them where rounds 1-3 did
+  // (thread (e_bb, e_r) of the first 256 finishes output row e_r of every tile for activation rows e_bb, e_bb + 16)
   const int e_bb = tid >> 4, e_r = tid & 15;
-  const bool e_on = tid < 256 && e_bb < a.M && e_r < ROWS;
+  const bool e_thr = tid < 256 && e_r < ROWS;
+  const bool e_on = e_thr && e_bb < a.M;
   constexpr int NRES = EPI == EPI_RESIDUAL ? TILES : 1, NSC = Q8 ? TILES : 1, NBIAS = EPI == EPI_STORE ? TILES : 1;
-  bf16_t e_res[NRES], e_scale[NSC], e_bias[NBIAS];   // (the scale of a bf16-dequantised int8 linear, !Q8, stays a late load)
+  bf16_t e_res[CS][NRES], e_scale[NSC], e_bias[NBIAS];   // (the scale of a bf16-dequantised int8 linear, !Q8, stays a late load)
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
-    if (t < NRES) e_res[t] = 0;
+#pragma unroll
+    for (int es = 0; es < CS; ++es)
+      if (t < NRES) e_res[es][t] = 0;
     if (t < NSC) e_scale[t] = 0;
     if (t < NBIAS) e_bias[t] = 0;
     if (e_on && a.late_epi != 1) {
-      if (EPI == EPI_RESIDUAL) e_res[t < NRES ? t : 0] = a.res[(int64_t)e_bb * a.ldr + (tile0 + t) * ROWS + e_r];
+      if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int es = 0; es < CS; ++es)
+          if (es * 16 + e_bb < a.M) e_res[es][t < NRES ? t : 0] = a.res[(int64_t)(es * 16 + e_bb) * a.ldr + (tile0 + t) * ROWS + e_r];
+      }
       if (Q8 && a.scale) e_scale[t < NSC ? t : 0] = a.scale[(tile0 + t) * 16 + e_r];
       if (EPI == EPI_STORE && a.bias) e_bias[t < NBIAS ? t : 0] = a.bias[(tile0 + t) * ROWS + e_r];
     }
@@ -532,9 +555,37 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     }
   };
 
-  float rstd[XS];
+  // sum of squares of one held / fetched register: the lane's chunk, sequentially over its pairs and elements
+  auto sumsq = [](const auto& regs, float ss) -> float {   // (regs: uint4[n], n a compile-time constant: stays in registers)
+    constexpr int n = (int)(sizeof(regs) / sizeof(uint4));
 #pragma unroll
-  for (int s = 0; s < XS; ++s) rstd[s] = 0.f;
+    for (int u = 0; u < n; ++u) {
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&regs[u]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf2f(e[j]);
+        ss = fmaf(f, f, ss);
+      }
+    }
+    return ss;
+  };
+  // ... then the eight chunks of the row by the tree (c ^ 1, c ^ 2, c ^ 4): three xor steps over the chunk lanes in the
+  // 8-row form; in the native form the lane's own two chunks (2 q, 2 q + 1) meet first, then lanes q ^ 1, q ^ 2
+  auto chunk_tree = [&](float ss0, float ss1) -> float {
+    float ss;
+    if (NAT) {
+      ss = ss0 + ss1;
+    } else {
+      ss = ss0;
+      ss += __shfl_xor(ss, 8, 64);
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    return ss;
+  };
+  float rstd[CS];
+#pragma unroll
+  for (int cs = 0; cs < CS; ++cs) rstd[cs] = 0.f;
   if (NORM && XH > 0) {
     // the norm weights travel through LDS (one 16-byte load per thread -- requested at the top of the kernel --, read
     // back as broadcasts after the statistics barrier): held in registers next to the fragments they cost the w1|w3
@@ -542,37 +593,27 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     // sum of squares: lane (chunk c = lane >> 3, row) sequentially over its pairs and elements, then the eight chunk
     // lanes of the row by an xor tree (c bit 0, 1, 2), then the waves in order
 #pragma unroll
-    for (int s = 0; s < XS; ++s) {
-      float ss = 0.f;
-#pragma unroll
-      for (int u = 0; u < XHN; ++u) {
-        const bf16_t* e = reinterpret_cast<const bf16_t*>(&xh[s][u]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float f = bf2f(e[j]);
-          ss = fmaf(f, f, ss);
-        }
-      }
-      ss += __shfl_xor(ss, 8, 64);
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      if (lane < 8) s_part[wave][s * 8 + lane] = ss;
+    for (int cs = 0; cs < CS; ++cs) {
+      const float ss = chunk_tree(sumsq(xh[NAT ? 2 * cs : 0], 0.f), NAT ? sumsq(xh[NAT ? 2 * cs + 1 : 0], 0.f) : 0.f);
+      if (lane < RS) s_part[wave][cs * RS + lane] = ss;
     }
     if (nw_has && a.late_epi == 2) nw_stage = reinterpret_cast<const uint4*>(a.norm_w)[tid];   // where round 4 began: behind the weight requests
     if (nw_has) s_nw[tid] = nw_stage;
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < XS; ++s) {
+    for (int cs = 0; cs < CS; ++cs) {
       float tot = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) tot += s_part[w][s * 8 + (lane & 7)];
-      rstd[s] = rsqrtf(tot / (float)a.K + a.eps);
+      for (int w = 0; w < WAVES; ++w) tot += s_part[w][cs * RS + (lane & (RS - 1))];
+      rstd[cs] = rsqrtf(tot / (float)a.K + a.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < XS; ++i)
 #pragma unroll
       for (int u = 0; u < XHN; ++u) {
-        const bf16x8 nf = norm_frag(xh[s][u], s_nw[(pbeg + u) * 8 + (lane >> 3)], rstd[s]);
-        xh[s][u] = *reinterpret_cast<const uint4*>(&nf);
+        const bf16x8 nf = norm_frag(xh[i][u], s_nw[(pbeg + u) * 8 + (k_off[i] >> 3)], rstd[NAT ? i >> 1 : 0]);
+        xh[i][u] = *reinterpret_cast<const uint4*>(&nf);
       }
-    }
   } else if (NORM && (a.K & 63) == 0 && (a.K >> 6) == SKINNY_XH * WAVES) {
     // A shape the held-fragment variants (XH > 0) also serve, e.g. the 9-16-row SwiGLU form next to the <= 8-row one:
     // the statistics take THEIR partition and reduction tree -- wave w over its own k-slice, lane (chunk, row)
@@ -581,32 +622,22 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     // (row_rstd's lane-strided sum + wave_sum is another fp32 order).  The fragments are not held: they are
     // re-read (L2 hits) by the product loop below.
 #pragma unroll
-    for (int s = 0; s < XS; ++s) {
-      uint4 xt[SKINNY_XH];
+    for (int cs = 0; cs < CS; ++cs) {
+      uint4 xt[NAT ? 2 : 1][SKINNY_XH];
 #pragma unroll
-      for (int u = 0; u < SKINNY_XH; ++u) xt[u] = *xptr(s, pbeg + u);
-      float ss = 0.f;
+      for (int h = 0; h < (NAT ? 2 : 1); ++h)
 #pragma unroll
-      for (int u = 0; u < SKINNY_XH; ++u) {
-        const bf16_t* e = reinterpret_cast<const bf16_t*>(&xt[u]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float f = bf2f(e[j]);
-          ss = fmaf(f, f, ss);
-        }
-      }
-      ss += __shfl_xor(ss, 8, 64);
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      if (lane < 8) s_part[wave][s * 8 + lane] = ss;
+        for (int u = 0; u < SKINNY_XH; ++u) xt[h][u] = *xptr(NAT ? 2 * cs + h : 0, pbeg + u);
+      const float ss = chunk_tree(sumsq(xt[0], 0.f), NAT ? sumsq(xt[NAT ? 1 : 0], 0.f) : 0.f);
+      if (lane < RS) s_part[wave][cs * RS + lane] = ss;
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < XS; ++s) {
+    for (int cs = 0; cs < CS; ++cs) {
       float tot = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) tot += s_part[w][s * 8 + (lane & 7)];
-      rstd[s] = rsqrtf(tot / (float)a.K + a.eps);
+      for (int w = 0; w < WAVES; ++w) tot += s_part[w][cs * RS + (lane & (RS - 1))];
+      rstd[cs] = rsqrtf(tot / (float)a.K + a.eps);
     }
   } else if (NORM) {
     for (int r = wave; r < a.M; r += WAVES) {
@@ -615,33 +646,32 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < XS; ++s) rstd[s] = s_rstd[min(s * 8 + (lane & 7), a.M - 1)];
+    for (int cs = 0; cs < CS; ++cs) rstd[cs] = s_rstd[min(cs * RS + (lane & (RS - 1)), a.M - 1)];
   }
 
-  f32x4 acc[2 * XS][TILES];   // [2 s + tile-of-pair]: row set s, valid in columns 0-7 (tile 0) / 8-15 (tile 1)
+  // [2 cs + k-tile of the pair]: 8-row form valid in columns 0-7 (k-tile 0) / 8-15 (k-tile 1); native: all 16 columns
+  f32x4 acc[NACC][TILES];
 #pragma unroll
-  for (int i = 0; i < 2 * XS; ++i)
+  for (int i = 0; i < NACC; ++i)
 #pragma unroll
     for (int t = 0; t < TILES; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto frag = [&](int s, int p) -> bf16x8 {  // activation (optionally normalised) fragment of k-tile pair p
-    uint4 xv = *xptr(s, p);
+  auto frag = [&](int i, int p) -> bf16x8 {  // activation (optionally normalised) register i of k-tile pair p
+    uint4 xv = *xptr(i, p);
     if (NORM) {
-      uint4 nv = *reinterpret_cast<const uint4*>(nbase + (int64_t)p * 128 + (uint32_t)f_off * 2u);
-      return norm_frag(xv, nv, rstd[s]);
+      uint4 nv = *reinterpret_cast<const uint4*>(nbase + (int64_t)p * 128 + k_off[i] * 2u);
+      return norm_frag(xv, nv, rstd[NAT ? i >> 1 : 0]);
     }
     return *reinterpret_cast<bf16x8*>(&xv);
   };
   auto mma_pair = [&](int slot, const bf16x8* xs) {   // one k-tile pair: weights of ring slot `slot`, fragments xs[XS]
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 w0 = wa[t][slot][0], w1 = wa[t][slot][1];
-      if (Q8) unpack_q8(wa[t][slot][0], w0, w1);
+      u32x4 w[2] = {wa[t][slot][0], wa[t][slot][1]};
+      if (Q8) unpack_q8(wa[t][slot][0], w[0], w[1]);
 #pragma unroll
-      for (int s = 0; s < XS; ++s) {
-        acc[2 * s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xs[s], acc[2 * s][t], 0, 0, 0);
-        acc[2 * s + 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xs[s], acc[2 * s + 1][t], 0, 0, 0);
-      }
+      for (int i = 0; i < NACC; ++i)
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w[i & 1]), xs[NAT ? i : 0], acc[i][t], 0, 0, 0);
     }
   };
 
@@ -658,19 +688,18 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
           u32x4 w0, w1;
           unpack_q8(wa[t][slot][0], w0, w1);
           if (more) wa[t][slot][0] = wload<NT>(wptr(t, pbeg + u + UNR));
-#pragma unroll
-          for (int s = 0; s < XS; ++s) {
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&xh[s][u]);
-            acc[2 * s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xv, acc[2 * s][t], 0, 0, 0);
-            acc[2 * s + 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xv, acc[2 * s + 1][t], 0, 0, 0);
+          {   // (int8: the 8-row form only)
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&xh[0][u]);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xv, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xv, acc[1][t], 0, 0, 0);
           }
         } else {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int s = 0; s < XS; ++s)
-              acc[2 * s + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][slot][h]),
-                                                                           *reinterpret_cast<const bf16x8*>(&xh[s][u]), acc[2 * s + h][t], 0, 0, 0);
+            for (int cs = 0; cs < CS; ++cs)
+              acc[2 * cs + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][slot][h]),
+                                                                            *reinterpret_cast<const bf16x8*>(&xh[NAT ? 2 * cs + h : 0][u]), acc[2 * cs + h][t], 0, 0, 0);
             if (more) wa[t][slot][h] = wload<NT>(wptr(t, 2 * (pbeg + u + UNR) + h));
           }
         }
@@ -718,39 +747,44 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
         if (p + u < pend) mma_pair(u, xs[u]);
     }
   }
-  // fold: tile 1's sums sit in columns 8-15 of the same rows; row set 1 (rows 8-15) moves to columns 8-15
+  // fold: the sums over k-tile 0 and k-tile 1 of the pairs meet -- 8-row form: tile 1's sit in columns 8-15 of the same
+  // rows; native: same columns -- and land in acc[2 cs], column = activation row (mod 16)
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float v = acc[0][t][j] + dpp_row_shl8(acc[1][t][j]);
-      if (XS == 2) {
-        const float v1 = acc[2 * (XS - 1)][t][j] + dpp_row_shl8(acc[2 * (XS - 1) + 1][t][j]);
-        const float v1s = dpp_row_shr8(v1);   // every lane executes the DPP move (a disabled source lane reads as invalid)
-        v = (b < 8) ? v : v1s;
+      if (NAT) {
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) acc[2 * cs][t][j] = acc[2 * cs][t][j] + acc[2 * cs + 1][t][j];
+      } else {
+        acc[0][t][j] = acc[0][t][j] + dpp_row_shl8(acc[1][t][j]);
       }
-      acc[0][t][j] = v;
     }
   if (!Q8 && (KT & 1) && wave == WAVES - 1) {  // unpaired last k-tile (plain k order), after the fold: same in every variant
     const int kt = KT - 1;
-    const int row = b < a.M ? b : 0;
-    uint4 xv = *reinterpret_cast<const uint4*>(a.x + (int64_t)row * a.ldx + kt * 32 + g * 8);
-    bf16x8 xb;
-    if (NORM) {
-      uint4 nv = *reinterpret_cast<const uint4*>(a.norm_w + kt * 32 + g * 8);
-      xb = norm_frag(xv, nv, s_rstd[row]);
-    } else {
-      xb = *reinterpret_cast<bf16x8*>(&xv);
-    }
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-      u32x4 wv = wload<NT>(wptr(t, kt));
-      acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[0][t], 0, 0, 0);
+    for (int cs = 0; cs < CS; ++cs) {
+      const int row = cs * 16 + b < a.M ? cs * 16 + b : 0;
+      uint4 xv = *reinterpret_cast<const uint4*>(a.x + (int64_t)row * a.ldx + kt * 32 + g * 8);
+      bf16x8 xb;
+      if (NORM) {
+        uint4 nv = *reinterpret_cast<const uint4*>(a.norm_w + kt * 32 + g * 8);
+        xb = norm_frag(xv, nv, s_rstd[row]);
+      } else {
+        xb = *reinterpret_cast<bf16x8*>(&xv);
+      }
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        u32x4 wv = wload<NT>(wptr(t, kt));
+        acc[2 * cs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[2 * cs][t], 0, 0, 0);
+      }
     }
   }
 
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[0][t];
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) *reinterpret_cast<f32x4*>(&red[wave][t][cs * 256 + lane * 4]) = acc[2 * cs][t];
   __syncthreads();
 
   if constexpr (KSL > 1) {
@@ -802,15 +836,18 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     __syncthreads();
   }
 
-  if (e_on) {
-    const int bb = e_bb, r = e_r;  // consecutive threads -> consecutive output columns
-    const int ridx = (((r >> 2) * 16) + bb) * 4 + (r & 3);
+  if (e_thr) {
+#pragma unroll
+   for (int es = 0; es < CS; ++es) {
+    const int bb = es * 16 + e_bb, r = e_r;  // consecutive threads -> consecutive output columns
+    if (bb >= a.M) break;
+    const int ridx = es * 256 + (((r >> 2) * 16) + e_bb) * 4 + (r & 3);
     float v[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
       bf16_t sc = 0;
       if (a.late_epi == 1 || !Q8) {
-        if (EPI == EPI_RESIDUAL && a.late_epi == 1) e_res[t < NRES ? t : 0] = a.res[(int64_t)bb * a.ldr + (tile0 + t) * ROWS + r];
+        if (EPI == EPI_RESIDUAL && a.late_epi == 1) e_res[es][t < NRES ? t : 0] = a.res[(int64_t)bb * a.ldr + (tile0 + t) * ROWS + r];
         if (a.scale) sc = a.scale[(tile0 + t) * 16 + r];
         if (EPI == EPI_STORE && a.bias && a.late_epi == 1) e_bias[t < NBIAS ? t : 0] = a.bias[(tile0 + t) * ROWS + r];
       } else {
@@ -829,7 +866,7 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     } else if (EPI == EPI_RESIDUAL) {
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
-        a.out[(int64_t)bb * a.ldo + (tile0 + t) * ROWS + r] = f2bf(bf2f(e_res[t < NRES ? t : 0]) + v[t]);
+        a.out[(int64_t)bb * a.ldo + (tile0 + t) * ROWS + r] = f2bf(bf2f(e_res[es][t < NRES ? t : 0]) + v[t]);
     } else {  // SwiGLU: even tiles = gate rows, odd tiles = up rows (llama.py:987)
 #pragma unroll
       for (int t = 0; t < TILES; t += 2) {
@@ -839,6 +876,7 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
         a.out[(int64_t)bb * a.ldo + n] = f2bf(gate * up);
       }
     }
+   }
   }
 }
 
@@ -851,15 +889,17 @@ static int skinny_late_epi() {   // FMI_GEMV_LATE_EPI=1: residual / scale / bias
   static const int on = []() { const char* e = getenv("FMI_GEMV_LATE_EPI"); return e ? atoi(e) : 0; }();
   return on;
 }
-// Rows 9-16 (XR = 16): the held fragments of TWO row sets (40 registers) push the SwiGLU variant to 128 registers + spills
-// at two work-groups per CU, so its 608 work-groups need a second, nearly empty round (31.7 us against 20.4 at M = 8);
-// with the round-3 prologue it fits 80 registers = three work-groups per CU = one round.  FMI_GEMV_WIDE_HOLD: 0 = no wide
-// variant holds, 1 (default) = all but SwiGLU hold, 2 = all hold (A/B runs).
+// Rows 9-16 (XR = 16): held fragments are TWO registers per pair (40 registers at K = 2560), which pushes the SwiGLU
+// variant past 80 registers = two work-groups per CU, so its 608 work-groups need a second, nearly empty round (measured
+// with round 4's two-row-set form: 31.7 us against 20.4 at M = 8); with the round-3 prologue it fits three work-groups
+// per CU = one round.  FMI_GEMV_WIDE_HOLD: 0 = no wide variant holds, 1 (default) = all but SwiGLU hold, 2 = all hold
+// (A/B runs).  Rows 17-32 (XR = 32, the merged fast pass of a batch of 9-16) never hold: 80 registers of fragments.
 static int skinny_wide_hold() {
   static const int v = []() { const char* e = getenv("FMI_GEMV_WIDE_HOLD"); return e ? atoi(e) : 1; }();
   return v;
 }
 static bool skinny_can_hold(const LinearArgs& a, int waves) {
+  if (a.M > 16) return false;
   if (a.M > 8 && (skinny_wide_hold() == 0 || (skinny_wide_hold() == 1 && a.epi == EPI_SILU))) return false;
   return a.norm_w != nullptr && (a.K % 64) == 0 && a.K / 64 == SKINNY_XH * waves && skinny_hold_enabled();
 }
@@ -869,12 +909,13 @@ static int launch_skinny_t(const LinearArgs& a0, hipStream_t s) {
   LinearArgs a = a0;
   a.late_epi = skinny_late_epi();
   const bool norm = a.norm_w != nullptr;
-  const bool wide = a.M > 8;
+  const bool wide = a.M > 8, wide2 = a.M > 16;
   const bool hold = skinny_can_hold(a, WAVES);
   dim3 grid(a.N / (16 * TILES)), block(WAVES * 64);
 #define FMI_LAUNCH_X(EPI_, NORM_, XH_)                                                                                       \
   do {                                                                                                                      \
-    if (wide) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 16, true, false, 16, XH_>), grid, block, 0, s, a); \
+    if (wide2) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 32, true, false, 16, 0>), grid, block, 0, s, a); \
+    else if (wide) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 16, true, false, 16, XH_>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 8, true, false, 16, XH_>), grid, block, 0, s, a);       \
   } while (0)
 #define FMI_LAUNCH(EPI_)                                          \
@@ -907,7 +948,7 @@ static int launch_skinny_t(const LinearArgs& a0, hipStream_t s) {
 // tilings leave CUs idle -- wo / w2 (N = 2560: 10 rows x 256 work-groups) and wqkv (N = 6144: 2 x 12 rows x 256).
 // Measured on MI355X (tools/gemv_rows_bench.hip, profiles/r03_gemv_rows_bench.txt), bit-identical outputs:
 // wo 6.5-6.6 -> 6.3 us, w2 12.4-14.7 -> 12.2, wqkv 10.3-10.5 -> 10.05; decode frame 4.73 -> 4.60 ms.
-// Round 4: batches of 9-16 rows stream the same copies (XR = 16).
+// Round 4: batches of 9-16 rows stream the same copies (XR = 16); round 6: 17-32 rows too (XR = 32).
 template <int WAVES, int UNR, int TILES, int ROWS, int EPI_, bool NORM_>
 static int launch_skinny_rows(const LinearArgs& a, const RowPlan& p, hipStream_t s) {
   LinearArgs b = a;
@@ -916,7 +957,9 @@ static int launch_skinny_rows(const LinearArgs& a, const RowPlan& p, hipStream_t
   constexpr int XH_ = NORM_ ? SKINNY_XH : 0;
   const bool hold = NORM_ && skinny_can_hold(a, WAVES);
   const dim3 grid(p.wgs), block(WAVES * 64);
-  if (a.M > 8) {
+  if (a.M > 16) {
+    hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 32, true, false, ROWS, 0>), grid, block, 0, s, b);
+  } else if (a.M > 8) {
     if (hold) hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 16, true, false, ROWS, XH_>), grid, block, 0, s, b);
     else hipLaunchKernelGGL((linear_skinny_kernel<WAVES, EPI_, NORM_, UNR, TILES, 16, true, false, ROWS, 0>), grid, block, 0, s, b);
   } else {
@@ -945,7 +988,7 @@ bool skinny_rows_supported(int N, int K, int epi, bool norm) {
 // (The norm-fused variants were VALU-bound on software bf16 rounding until norm_frag moved to
 // v_cvt_pk_bf16_f32: 26.4 -> 21.8 us and 13.5 -> 10.0 us.)
 int launch_linear_skinny(const LinearArgs& a, hipStream_t s) {
-  FMI_REQUIRE(a.M >= 1 && a.M <= 16, "linear_skinny: M=%d not in [1,16]", a.M);
+  FMI_REQUIRE(a.M >= 1 && a.M <= 32, "linear_skinny: M=%d not in [1,32]", a.M);
   FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0, "linear_skinny: bad shape N=%d K=%d", a.N, a.K);
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_skinny: SwiGLU needs N %% 32");
   const int KT = a.K / 32;

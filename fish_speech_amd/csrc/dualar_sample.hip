@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   int tok = (row < 0) ? 0 : (ids ? ids[row] : row);
 
   if (a.mode == 1) {  // fast codebook draw
+    if (a.forced) tok = a.forced[(int64_t)slot * a.st.ncb1 + 1 + a.cb];
     if (tid == 0) a.st.cur[(int64_t)slot * a.st.ncb1 + 1 + a.cb] = tok;
   } else {
     // second draw at RAS_HIGH_TEMP / RAS_HIGH_TOP_P (inference.py:126-131); always consumed
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       if (tid == 0) a.out_tok[b] = tok;
       return;
     }
+    if (a.forced) tok = a.forced[(int64_t)slot * a.st.ncb1];
     int cb0 = tok - a.sem_begin;
     cb0 = cb0 < 0 ? 0 : (cb0 > a.cbs - 1 ? a.cbs - 1 : cb0);
     if (tid == 0) {
@@ -500,10 +502,22 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   // and at most a few hundred of the 4097 are.  After the barrier every wave knows the smallest distance that already
   // holds k keys of the WHOLE row: nothing farther from the maximum can be among the k largest, so the waves only hand
   // on their keys inside that distance instead of each finding its own k largest by an eight-step radix descent.
+  // (a thread's keys are CONTIGUOUS entries: runs of keys in one bucket -- a flat or masked row puts all 17 into the same
+  // one -- are counted in a register and added once, so the worst row costs 256 LDS adds, not 4097: ADVICE r05)
+  {
+    int cb = -1, cc = 0;
 #pragma unroll
-  for (int j = 0; j < SMALL_EPT; ++j) {
-    const uint32_t d = kmax - kr[j];
-    if (kr[j] != 0u && d < 512u) atomicAdd(&sh.bkw[wave][d >> 4], 1);
+    for (int j = 0; j < SMALL_EPT; ++j) {
+      const uint32_t d = kmax - kr[j];
+      const int bk = (kr[j] != 0u && d < 512u) ? (int)(d >> 4) : -1;
+      if (bk != cb) {
+        if (cc) atomicAdd(&sh.bkw[wave][cb], cc);
+        cb = bk;
+        cc = 0;
+      }
+      cc += bk >= 0;
+    }
+    if (cc) atomicAdd(&sh.bkw[wave][cb], cc);
   }
   __syncthreads();
   const float sumexp = sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3];
@@ -681,6 +695,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
   tok = small_draw(v, cum, vid, lane, k, temperature, top_p, seed, 0u /* stream: an utterance's draws depend on its seed only, not on the slot it occupies */, (uint32_t)frame, (uint32_t)draw0);
   if (a.dbg_stop == 7) return;
   if (a.mode == 1) {
+    if (a.forced) tok = a.forced[(int64_t)slot * a.st.ncb1 + 1 + a.cb];
     if (lane == 0) a.st.cur[(int64_t)slot * a.st.ncb1 + 1 + a.cb] = tok;
   } else {
     const bool second = (a.mode == 0) || (a.prev != nullptr);
@@ -699,6 +714,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
       if (lane == 0) a.out_tok[b] = tok;
       return;
     }
+    if (a.forced) tok = a.forced[(int64_t)slot * a.st.ncb1];
     int cb0 = tok - a.sem_begin;
     cb0 = cb0 < 0 ? 0 : (cb0 > a.cbs - 1 ? a.cbs - 1 : cb0);
     if (lane == 0) {

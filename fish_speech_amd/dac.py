@@ -248,6 +248,7 @@ class MiDAC:
         self._planes = 2                       # decode-side arithmetic outside autocast (set_precision)
         self._lock = threading.RLock()         # (precision, call) pairs of concurrent request threads stay together
         self._async = False
+        self._keep_async: list = []
         self._fp32_streams: set = set()        # open streams that fell back to the fp32 matrix cores (_decode_call)
 
     def __del__(self):
@@ -314,16 +315,30 @@ class MiDAC:
         torch.cuda.current_stream(self.device).synchronize()
         return self
 
-    def weights_ready(self):
-        check(self.lib.fmi_dac_weights_ready(self._h))
+    def weights_ready(self, stream=None):
+        """As MiDualAR.weights_ready: the codec's stream is ordered after `stream` (default: the current one)."""
+        s = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        check(self.lib.fmi_dac_weights_ready(self._h, s))
 
     # ---- running beside the Dual-AR frame loop (fishmi.h: fmi_dac_set_async / fmi_dac_set_stream_options)
     def set_async(self, enable: bool):
         """encode / decode calls return once enqueued on the codec's own stream and no longer make torch's current stream
         wait; order a consumer with `wait_stream()` or wait with `synchronize()` before reading the result."""
+        if self._async and not enable:
+            self.synchronize()     # drains the kept temporaries and a pending overflow flag of the async calls
         check(self.lib.fmi_dac_set_async(self._h, int(bool(enable))))
         self._async = bool(enable)
         return self
+
+    def _hold(self, *tensors):
+        """Internal temporaries of a call (index copies, padded audio): alive until the codec's stream is done with them.
+        Synchronous mode: the caller's stream waits for the call, so the last call's are enough.  Async mode: nothing
+        orders torch's allocator after the codec stream, so every call's temporaries are kept until `synchronize()` /
+        `wait_stream()`."""
+        if self._async:
+            self._keep_async.extend(tensors)
+        else:
+            self._keep = tensors
 
     def set_background(self, lds_floor_bytes: int):
         """Floor under the dynamic LDS of the decode-side conv kernels (> 80 KiB: one work-group per CU, so that another
@@ -334,10 +349,20 @@ class MiDAC:
     def wait_stream(self):
         """order torch's current stream after the codec calls enqueued so far (no host wait)"""
         check(self.lib.fmi_dac_wait(self._h, self._stream()))
+        for t in self._keep_async:      # freed blocks are reused on torch's stream, which is now behind the codec's
+            t.record_stream(torch.cuda.current_stream(self.device))
+        self._keep_async = []
 
     def synchronize(self):
-        """host wait for everything enqueued on the codec's stream"""
+        """host wait for everything enqueued on the codec's stream.  In async mode with check_overflow this is also where
+        an fp16-range overflow of the calls since the last synchronize is reported: an async call cannot be redone on
+        the fp32 matrix cores behind the caller's back (its output was already handed out), so it raises."""
         check(self.lib.fmi_dac_synchronize(self._h))
+        self._keep_async = []
+        if self._async and self.check_overflow and self._planes == 2 and self.fp16_overflowed():
+            raise _lib.FishmiError("an operand of the fp16-split codec arithmetic left the fp16 range during an async "
+                                   "call; its audio is saturated -- redo the call with set_async(False) (which falls "
+                                   "back to the fp32 matrix cores) or set_precision(0)")
 
     def set_stream_options(self, priority: int = 0, cu_mask: Optional[Sequence[int]] = None):
         """priority: -1 highest, 0 default, 1 lowest; cu_mask: 32-bit words, bit i = compute unit i may run this codec's
@@ -437,8 +462,10 @@ class MiDAC:
         T = N // fl
         idx = torch.empty(B, self.config.n_codebooks + 1, T, dtype=torch.int64, device=self.device)
         check(self.lib.fmi_dac_encode(self._h, C.c_void_p(audio.data_ptr()), B, N, C.c_void_p(idx.data_ptr()), self._stream()))
+        if self._async:
+            self.wait_stream()     # idx is consumed on torch's stream (and `lens` below is computed there)
         lens = torch.ceil(audio_lengths.to(self.device) / fl).long()
-        self._keep = audio
+        self._hold(audio)
         return idx, lens
 
     # ---- DAC.from_indices (modded_dac.py:925-927).  Clamps `indices` in place like rvq.py:354-359.
@@ -460,7 +487,7 @@ class MiDAC:
                 indices.copy_(work)  # the reference mutates its argument; keep that visible to the caller
             except Exception:
                 pass
-        self._keep = work
+        self._hold(work)
         return out.to(self.module_dtype) if self.module_dtype != torch.float32 else out
 
     # ---- ragged batch decode (the server's batched decode, tools/server/model_utils.py:61-86, over utterances of
@@ -524,7 +551,7 @@ class MiDAC:
             self._decode_call(self.lib.fmi_dac_decode_tail_cached, C.c_void_p(work.data_ptr()), B, T, int(t0),
                               C.c_int64(int(stream_id)), C.c_void_p(out.data_ptr()), self._stream(),
                               stream_id=int(stream_id))
-        self._keep = work
+        self._hold(work)
         return out
 
     _stream_ids = itertools.count(1)
@@ -558,7 +585,7 @@ class MiDAC:
             raise ValueError(f"expected {self.config.latent_dim} latent channels, got {Cc}")
         out = torch.empty(B, 1, L * self.hop_length, dtype=torch.float32, device=self.device)
         self._decode_call(self.lib.fmi_dac_decode_latent, C.c_void_p(z.data_ptr()), B, L, C.c_void_p(out.data_ptr()), self._stream())
-        self._keep = z
+        self._hold(z)
         return out
 
     def debug_z(self, B: int) -> torch.Tensor:

@@ -37,7 +37,12 @@ def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_bytes: int = 1 << 30
 
 
 def broadcast_arena(model, src: int = 0, group=None, chunk_bytes: int = 1 << 30):
-    """Replicate a loaded model's packed weight arena to every rank, then mark it ready there."""
+    """Replicate a loaded model's packed weight arena to every rank, then mark it ready there.
+
+    Ordering is the product's, not the caller's: a blocking `dist.broadcast` returns with torch's current stream
+    ordered after the collective (RCCL runs it on its own stream), and `weights_ready()` makes the model's private
+    stream -- on which the first prefill derives the row-balanced copies and the q|k|v table FROM the arena -- wait
+    for the current stream.  No device synchronize is needed after this call."""
     import torch.distributed as dist
 
     broadcast_buffer(model.arena, src=src, chunk_bytes=chunk_bytes, group=group)

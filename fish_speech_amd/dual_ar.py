@@ -303,9 +303,12 @@ class MiDualAR:
         torch.cuda.current_stream(self.device).synchronize()
         return self
 
-    def weights_ready(self):
-        """After a broadcast filled the arena on a non-loading rank."""
-        check(self.lib.fmi_dualar_weights_ready(self._h))
+    def weights_ready(self, stream=None):
+        """After a broadcast / copy filled the arena on a non-loading rank.  `stream` (default: torch's current stream
+        on this device) is the stream that work was enqueued on; the handle's own stream is ordered after it inside the
+        library, so no host synchronize is needed before the first prefill derives its tables from the arena."""
+        s = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        check(self.lib.fmi_dualar_weights_ready(self._h, s))
 
     @classmethod
     def from_state_dict(cls, config, state, device="cuda:0", im_end_id=None) -> "MiDualAR":
@@ -586,6 +589,21 @@ class MiDualAR:
         p = C.c_void_p()
         check(self.lib.fmi_dualar_set_trace(self._h, int(enable), C.byref(p)))
         self._trace_ptr = p.value
+
+    def fast_chain_forced(self, hidden: torch.Tensor, forced: torch.Tensor, slots, table: bool = True) -> torch.Tensor:
+        """Test seam (fishmi.h: fmi_dualar_fast_chain_forced): the fast chain of one frame for `slots` from the normed
+        hidden rows `hidden` (B, dim), every draw replaced by `forced` (B, 1 + num_codebooks), on the frame loop's own
+        path.  Returns the fast logits (B, num_codebooks, codebook_size); row 0 of each is not computed."""
+        cfg = self.config
+        B = len(slots)
+        hid = hidden.reshape(B, -1).to(device=self.device, dtype=torch.bfloat16).contiguous()
+        frc = forced.reshape(B, cfg.num_codebooks + 1).to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.zeros(B, cfg.num_codebooks, cfg.codebook_size, dtype=torch.bfloat16, device=self.device)
+        sl = (C.c_int32 * B)(*[int(x) for x in slots])
+        check(self.lib.fmi_dualar_fast_chain_forced(self._h, B, sl, C.c_void_p(hid.data_ptr()), C.c_void_p(frc.data_ptr()),
+                                                    int(bool(table)), C.c_void_p(out.data_ptr()), self._stream()))
+        self._keep = (hid, frc)
+        return out
 
     def fast_trace(self, B: int = 1) -> torch.Tensor:
         cfg = self.config

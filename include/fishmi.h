@@ -76,8 +76,12 @@ int fmi_dualar_load_tensor_int8(fmi_dualar* h, const char* name, const void* wei
 /* Call once after all tensors are loaded (rank 0 before the broadcast) to build derived
  * tables inside the arena (live LM-head rows, RoPE tables). */
 int fmi_dualar_finalize_weights(fmi_dualar* h, void* stream);
-/* Call on every rank after the arena content is in place (locally loaded or broadcast). */
-int fmi_dualar_weights_ready(fmi_dualar* h);
+/* Call on every rank whose arena was filled from outside (a broadcast, a device copy) instead of load_tensor +
+ * finalize.  `stream` = the stream that work was enqueued on: the handle's private stream is made to wait for it
+ * (an event, no host wait), so the derived tables the first prefill builds from the arena never read it early and
+ * the caller needs no device synchronize between the collective and the first call.  Replaces nothing upstream:
+ * the reference reads the checkpoint on every rank (tools/vqgan/extract_vq.py:161-207 starts one process per GPU). */
+int fmi_dualar_weights_ready(fmi_dualar* h, void* stream);
 
 /* KV-cache page pool + per-slot state for up to max_batch concurrent utterances of up to
  * max_seq_len positions.  Replaces DualARTransformer.setup_caches (llama.py:307-324,708-722). */
@@ -175,8 +179,20 @@ int fmi_dualar_derived_info(fmi_dualar* h, int* row_copies, int* table_rows, int
 int fmi_dualar_debug_ptrs(fmi_dualar* h, void** slow_logits, int* n_live, int* ld_logits,
                           void** live_ids, void** hidden, void** fast_logits);
 /* If enabled, every fast step's logits are also copied to a trace buffer
- * [B][num_codebooks][codebook_size] (bf16) returned here. */
+ * [B][num_codebooks][codebook_size] (bf16) returned here.  enable = 1: traced frames run the plain GEMV path (no
+ * tabulated layer-0 q|k|v); 2: traced frames keep the frame loop's own path (table in use).  Eager either way. */
 int fmi_dualar_set_trace(fmi_dualar* h, int enable, void** fast_trace);
+/* Test seam (float parity of the fast chain at every codebook position, on the frame loop's own path): steps 6-8 of
+ * decode_one_token_ar (fish_speech/models/text2semantic/inference.py:148-176 -- forward_generate_fast at position 0 on
+ * the hidden state, then one position per codebook) for B slots (host array slot_ids) from the NORMED hidden rows
+ * `hidden_normed_dev` (bf16 [B][dim], what forward_generate returns, llama.py:459-461), executed exactly as a decode
+ * frame executes them (batch GEMV, merged positions 0/1 per fmi_dualar_set_fast_merge, the tabulated layer-0 q|k|v
+ * when table != 0), with every draw REPLACED by `forced_dev` (int32 [B][1 + num_codebooks]: slow token id, then the
+ * codes).  fast_logits_out_dev: bf16 [B][num_codebooks][codebook_size], rows 1.. = forward_generate_fast's logits at
+ * positions 1..num_codebooks-1 (position 0's are never computed: the reference discards them).  The slots must have
+ * been prefilled (their sampling parameters are read); their frame counters advance as after a decode frame. */
+int fmi_dualar_fast_chain_forced(fmi_dualar* h, int B, const int32_t* slot_ids, const void* hidden_normed_dev,
+                                 const int32_t* forced_dev, int table, void* fast_logits_out_dev, void* stream);
 /* 1 = keep generating past <|im_end|> (fixed-length synthetic benchmarks). */
 int fmi_dualar_set_ignore_eos(fmi_dualar* h, int enable);
 /* Disable hipGraph replay (eager launches) -- used by tests/profiling. */
@@ -187,7 +203,8 @@ int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl);
 /* Fast transformer positions 0 and 1 of a frame (the two forward_generate_fast calls of inference.py:148-149 and :166,
  * whose inputs are both known once the slow token is drawn): 1 = one pass over the fast weights with 2 x batch rows
  * (default when 2 x batch <= 16, bf16 weights, fast_dim == dim), 0 = two passes (rounds 1-3; kept for A/B parity runs).
- * Results are bit-identical either way. */
+ * Results are bit-identical either way, tokens and float taps (tests/test_s2_parity_gpu.py:
+ * test_merged_fast_positions_equal_the_two_pass_path_bit_for_bit_at_batch_5_and_8). */
 int fmi_dualar_set_fast_merge(fmi_dualar* h, int enable);
 /* Dispatch priority of the handle's private stream (-1 highest, 0 default, 1 lowest); the stream is re-created, graphs
  * are re-captured.  For a frame loop that shares the GPU with another queue (the codec decode of the previous batch:
@@ -266,7 +283,8 @@ void fmi_dac_destroy(fmi_dac* h);
 int fmi_dac_load_tensor(fmi_dac* h, const char* name, const float* src, int ndim,
                         const int64_t* dims, int src_is_device, void* stream);
 int fmi_dac_finalize_weights(fmi_dac* h, void* stream);
-int fmi_dac_weights_ready(fmi_dac* h);
+/* As fmi_dualar_weights_ready: marks an externally filled arena ready and orders the handle's stream after `stream`. */
+int fmi_dac_weights_ready(fmi_dac* h, void* stream);
 /* Arithmetic of the decode-side contractions (from_indices / decode / decode_tail; the encoder always uses the fp32
  * matrix cores so that its codes stay bit-comparable):
  *   2 (default) fp16 matrix cores on a two-term split of both operands, low part scaled by 2^11: three products, two

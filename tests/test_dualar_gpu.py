@@ -819,16 +819,119 @@ def test_s2_shape_random_weights_prompt_of_250_and_decode_positions_across_a_pag
         frame[0, 0, 0] = frame[0, 1, 0] + cfg.semantic_begin_id
         want_logits, want_hidden = orc.forward_generate(frame, torch.tensor([pos]), math_backend=True)
         ex_logits, ex_hidden = exact.forward_generate(frame, torch.tensor([pos]), math_backend=True)
-        model.load_state_dict({k: (v.float() * 0.5).to(v.dtype) for k, v in w2_dev.items()})
-        r = model.forward_generate(frame.to(DEV), torch.tensor([pos], device=DEV))
-        with pytest.raises(AssertionError):
-            close(r.hidden_states, want_hidden, ex_hidden, f"position {pos} hidden, every slow w2 halved", False)
-        with pytest.raises(AssertionError):
-            close(r.logits[0, 0].cpu()[ids], want_logits[0, 0][ids], ex_logits[0, 0][ids], f"position {pos} logits, every slow w2 halved", False)
-        model.load_state_dict(w2_dev)
+        try:   # (the shared model gets its weights back even if a check below fails: ADVICE r05)
+            model.load_state_dict({k: (v.float() * 0.5).to(v.dtype) for k, v in w2_dev.items()})
+            r = model.forward_generate(frame.to(DEV), torch.tensor([pos], device=DEV))
+            with pytest.raises(AssertionError):
+                close(r.hidden_states, want_hidden, ex_hidden, f"position {pos} hidden, every slow w2 halved", False)
+            with pytest.raises(AssertionError):
+                close(r.logits[0, 0].cpu()[ids], want_logits[0, 0][ids], ex_logits[0, 0][ids], f"position {pos} logits, every slow w2 halved", False)
+        finally:
+            model.load_state_dict(w2_dev)
         r = model.forward_generate(frame.to(DEV), torch.tensor([pos], device=DEV))
         close(r.logits[0, 0].cpu()[ids], want_logits[0, 0][ids], ex_logits[0, 0][ids], f"position {pos} logits, weights restored", False)
         close(r.hidden_states, want_hidden, ex_hidden, f"position {pos} hidden, weights restored", False)
+    finally:
+        torch.set_num_threads(nthreads)
+
+
+def test_s2_shape_fast_chain_every_codebook_position_on_the_frame_loop_path(s2_model):
+    """the float check of the FAST chain at the BASELINE width at ALL of its positions, on the path the
+    benchmark runs.  Eight (hidden, frame) pairs -- normed hidden rows taken from the model's own slow forward over eight
+    short prompts, so they are real hidden states -- go through `fast_chain_forced`: tail() as a decode frame runs it
+    at batch 8 (merged positions 0/1, batch GEMV, the tabulated layer-0 q|k|v), every draw replaced by the frame the
+    bf16 CPU oracle's argmax dictates (teacher forcing: a near-tie cannot fork the chain).  The same rows run through
+    the bf16 oracle and the fp32-exact oracle.  At each of positions 1..9 (position 0's logits do not exist: the
+    reference discards them, inference.py:148-149; its K/V feed every later position) the HIP logits must be as close
+    to the exact model as the reference's bf16 CPU arithmetic is (<= 1.3 x its relative L2, rows pooled), with the
+    table ON and OFF and merged / two-pass; ON == OFF and merged == two-pass bit for bit.  A fault injected into the
+    fast layers of the HIP model (every fast w2 x 0.5) must be refused."""
+    import dataclasses
+
+    import bench
+
+    cfg, model = s2_model
+    B, ncb = 8, cfg.num_codebooks
+    dev_state = bench.synthetic_state_on_device(cfg, torch.device(DEV))
+    fast_keys = [k for k in dev_state if k.startswith("fast_")]
+    w2_dev = {k: dev_state[k] for k in fast_keys if k.endswith("feed_forward.w2.weight")}
+    state = {k: dev_state[k].cpu() for k in fast_keys}
+    state["embeddings.weight"] = torch.zeros(1, cfg.dim, dtype=torch.bfloat16)     # (dtype marker only; no slow pass here)
+    del dev_state
+    ocfg = O.DualARConfig(**{f.name: getattr(cfg, f.name) for f in dataclasses.fields(O.DualARConfig)
+                             if hasattr(cfg, f.name)})
+    ocfg.n_layer, ocfg.max_seq_len = 0, 16
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(nthreads, 32))
+    try:
+        orc = O.DualAROracle(ocfg, state)
+        orc.setup_caches(B, 16)
+        exact = O.DualAROracle(ocfg, {k: v.float() for k, v in state.items()})
+        exact.setup_caches(B, 16)
+        # real hidden states: the slow forward of eight 6-token prompts (its parity is the two tests above)
+        g = torch.Generator().manual_seed(606)
+        hidden = []
+        for i in range(B):
+            x = torch.zeros(1, ncb + 1, 6, dtype=torch.int64)
+            x[0, 0] = torch.randint(0, 150000, (6,), generator=g)
+            hidden.append(model.forward_generate(x.to(DEV), torch.arange(6, device=DEV)).hidden_states.reshape(-1).cpu())
+        hidden = torch.stack(hidden)                                                  # (B, dim) bf16
+        code0 = torch.randint(0, cfg.codebook_size, (B,), generator=g)
+        # oracles, teacher-forced by the bf16 oracle's argmax
+        orc.forward_generate_fast(hidden, torch.tensor([0]))
+        exact.forward_generate_fast(hidden.float(), torch.tensor([0]))
+        forced = torch.zeros(B, ncb + 1, dtype=torch.int32)
+        forced[:, 0] = (code0 + cfg.semantic_begin_id).int()
+        forced[:, 1] = code0.int()
+        want, ideal, a = [], [], code0
+        for cb in range(1, ncb):
+            e = orc.fast_embeddings(a)
+            want.append(orc.forward_generate_fast(e, torch.tensor([cb])).reshape(B, -1))
+            ideal.append(exact.forward_generate_fast(e.float(), torch.tensor([cb])).reshape(B, -1))
+            a = want[-1].float().argmax(dim=-1)
+            forced[:, 1 + cb] = a.int()
+        del orc, exact, state
+
+        slots = list(range(B))
+        prompts = [torch.zeros(ncb + 1, 4, dtype=torch.int64) for _ in range(B)]
+
+        def run(table, merge):
+            model.set_fast_merge(merge)
+            model.prefill(slots, prompts, [4] * B, [model._sampling(0.7, 0.7, 1, 0)] * B)
+            out = model.fast_chain_forced(hidden, forced, slots, table=table).cpu()
+            for sl in slots:
+                model.release(sl)
+            return out
+
+        def rel(x, y):
+            return float((x.float() - y.float()).norm() / y.float().norm())
+
+        def check(got, what):
+            for cb in range(1, ncb):
+                w, i, gt = want[cb - 1], ideal[cb - 1], got[:, cb]
+                noise, e_ideal, e_orc = rel(w, i), rel(gt, i), rel(gt, w)
+                print(f"S2 fast chain ({what}), position {cb}: vs exact: HIP {e_ideal:.4f}, bf16 oracle {noise:.4f}; HIP vs oracle {e_orc:.4f}")
+                assert e_ideal <= 1.3 * noise + 1e-3, (what, cb)
+                assert e_orc <= 2.0 * noise + 1e-3, (what, cb)
+
+        got_on = run(True, True)
+        assert model.derived_info()["table_rows"] == cfg.codebook_size, "the table is not in use: this would not test the benchmark's path"
+        check(got_on, "table on, merged")
+        got_off = run(False, True)
+        check(got_off, "table off, merged")
+        assert torch.equal(got_on[:, 1:], got_off[:, 1:]), "tabulated layer-0 q|k|v changes bits"
+        got_two = run(True, False)
+        assert torch.equal(got_on[:, 1:], got_two[:, 1:]), "merged positions 0/1 change bits"
+        # fault injection on the HIP side, restored whatever happens
+        try:
+            model.load_state_dict({k: (v.float() * 0.5).to(v.dtype) for k, v in w2_dev.items()})
+            bad = run(True, True)
+            with pytest.raises(AssertionError):
+                check(bad, "every fast w2 halved")
+        finally:
+            model.load_state_dict(w2_dev)
+            model.set_fast_merge(True)
+        check(run(True, True), "weights restored")
     finally:
         torch.set_num_threads(nthreads)
 

@@ -31,8 +31,7 @@ def _replica_of(a, make):
     b = make()
     assert b.arena.numel() == a.arena.numel() and b.arena.data_ptr() != a.arena.data_ptr()
     b.arena.copy_(a.arena)
-    torch.cuda.synchronize()
-    b.weights_ready()
+    b.weights_ready()   # no host synchronize: the library orders the handle's stream after the copy
     return b
 
 
@@ -81,6 +80,35 @@ def test_dualar_replica_fed_by_the_arena_bytes_alone_generates_the_reference_tok
                          stop_on_im_end=False)
     for row in range(8):
         assert np.array_equal(out[row].numpy(), wants[row]), f"replica, ragged batch row {row}"
+    del B
+
+
+def test_replica_filled_on_a_side_stream_with_no_host_sync_before_its_first_prefill():
+    """The start-up ordering is the library's (fmi_dualar_weights_ready(h, stream)), not the harness's: the arena copy
+    is enqueued on a SIDE stream behind ~50 ms of busy work, so at the time `generate` is called the bytes are certainly
+    not there yet and torch's current stream knows nothing about the copy.  No synchronize anywhere between the copy
+    and the first prefill (which rebuilds 4.1 GB of row-balanced copies and the q|k|v table from the arena on the
+    handle's private stream).  The replica still returns the matrix the unmodified reference wrote."""
+    from fish_speech_amd.dual_ar import MiDualAR
+    from tests import test_s2_parity_gpu as S2
+
+    z, skw = S2._load("s2_plain")
+    cfg, A, _ = S2._model(skw)
+    B = MiDualAR(cfg, device=DEV, im_end_id=cfg.im_end_id)
+    B.setup_caches(2, 512)
+    B.arena.zero_()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(100_000_000)      # ~50 ms at 2 GHz: the copy below cannot have started when generate() runs
+        B.arena.copy_(A.arena, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    B.weights_ready(stream=side)
+    assert not done.query(), "the copy finished before the first call: the test would not see a missing order"
+    got = _gen(B, z)
+    assert np.array_equal(got, z["tokens"]), "replica read its arena before the side-stream copy landed"
+    assert B.derived_info()["loaded_tensors"] == 0
     del B
 
 

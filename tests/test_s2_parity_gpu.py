@@ -155,21 +155,24 @@ def _run_with_taps(model, prompts, seeds, frames, trace=True):
     return toks, bits(logits), bits(hidden), bits(fast)
 
 
-@pytest.mark.parametrize("B", [5, 8])
+@pytest.mark.parametrize("B", [5, 8, 12, 16])
 def test_merged_fast_positions_equal_the_two_pass_path_bit_for_bit_at_batch_5_and_8(B):
     """with 5..8 utterances the merged pass runs the fast GEMVs at M = 2 B = 10..16 rows -- the 16-row
     forms, whose SwiGLU variant takes its RMSNorm statistics in another kernel branch than the <= 8-row form of the two-pass
     path.  Both branches now share one partition and reduction tree; asserted on the FLOAT taps, not only on tokens:
     slow logits, hidden rows and the logits of all ten fast positions of the last frame are bit-identical with the
     merge on and off, as are the token matrices (and the rebuilt key / value 0 of fast_attn_kernel's merged form with
-    them: any difference there would move the position-1 logits)."""
+    them: any difference there would move the position-1 logits).
+    Round 6: B = 12 / 16 -- the merged pass at M = 24 / 32 rows (the GEMV's two-column-set form, XR = 32) against the
+    two-pass path at M = 12 / 16 (the native 16-row form)."""
     skw, prompts, seeds = _ragged_prompts()
+    prompts, seeds = prompts + prompts, seeds + seeds
     cfg, model, _ = _model(skw)
     for trace in (True, False):
         outs = {}
         for merge in (True, False):
             model.set_fast_merge(merge)
-            outs[merge] = _run_with_taps(model, prompts[:B], seeds[:B], frames=6, trace=trace)
+            outs[merge] = _run_with_taps(model, prompts[:B], seeds[:B], frames=6 if B <= 8 else 3, trace=trace)
         model.set_fast_merge(True)
         (t1, l1, h1, f1), (t0, l0, h0, f0) = outs[True], outs[False]
         for a, b in zip(t1, t0):
@@ -180,19 +183,26 @@ def test_merged_fast_positions_equal_the_two_pass_path_bit_for_bit_at_batch_5_an
 
 
 def test_rows_are_bit_identical_in_a_batch_of_8_and_in_a_batch_of_16():
-    """Batch invariance across the M = 8 / M = 16 kernel forms, on the float taps: the eight ragged
+    """Batch invariance across the M = 8 / M = 16 / M = 32 kernel forms, on the float taps: the eight ragged
     utterances alone, and twice over in a batch of 16 (slots i and i + 8 carry the same utterance) -- slow layers at
-    M = 16 (XR = 16 forms, SwiGLU without held fragments), fast positions unmerged above batch 8.  Every row's slow
-    logits, hidden state and fast logits equal its batch-8 bits."""
+    M = 16 (the native 16-row form, round 6; SwiGLU without held fragments), fast positions 0/1 merged at M = 32 (two
+    column sets) or, merge off, two passes at M = 16.  Every row's slow logits, hidden state and fast logits equal its
+    batch-8 bits, with the table in use (trace off: the benchmark's frame) and without."""
     skw, prompts, seeds = _ragged_prompts()
     cfg, model, _ = _model(skw)
-    t8, l8, h8, f8 = _run_with_taps(model, prompts, seeds, frames=4)
-    t16, l16, h16, f16 = _run_with_taps(model, prompts + prompts, seeds + seeds, frames=4)
-    for i in range(8):
-        assert torch.equal(t16[i], t8[i]) and torch.equal(t16[i + 8], t8[i]), i
-    for half in (slice(0, 8), slice(8, 16)):
-        assert torch.equal(l16[half], l8) and torch.equal(h16[half], h8), "slow taps depend on the batch size"
-        assert torch.equal(f16[half], f8), "fast logits depend on the batch size"
+    for trace in (True, False):
+        t8, l8, h8, f8 = _run_with_taps(model, prompts, seeds, frames=4, trace=trace)
+        for merge in (True, False):
+            model.set_fast_merge(merge)
+            try:
+                t16, l16, h16, f16 = _run_with_taps(model, prompts + prompts, seeds + seeds, frames=4, trace=trace)
+            finally:
+                model.set_fast_merge(True)
+            for i in range(8):
+                assert torch.equal(t16[i], t8[i]) and torch.equal(t16[i + 8], t8[i]), i
+            for half in (slice(0, 8), slice(8, 16)):
+                assert torch.equal(l16[half], l8) and torch.equal(h16[half], h8), "slow taps depend on the batch size"
+                assert torch.equal(f16[half], f8), f"fast logits depend on the batch size (merge={merge}, trace={trace})"
 
 
 def test_s2_int8_full_sequence_equals_the_reference_int8_run():

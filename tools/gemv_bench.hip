@@ -1,12 +1,12 @@
 // gemv_bench.hip -- micro-benchmark of the skinny (decode) linear on MI355X: the SHIPPED launcher per S2-Pro shape
-// (row-balanced copies included, as the frame runs them) at M = 1 / 8 / 12 / 16, next to a bare streaming read of the
+// (row-balanced copies included, as the frame runs them) at M = 1 / 8 / 12 / 16 / 24 / 32, next to a bare streaming read of the
 // same bytes.  Kernel variants are selected by the launcher's environment switches, so A/B = two runs:
 //   FMI_GEMV_NOHOLD=1    norm-fused variants with the round-3 prologue (statistics pass + fragments)
 //   FMI_GEMV_LATE_EPI=1  residual / scale / bias loaded after the last barrier (rounds 1-3)
 // Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemv_bench.hip \
 //                               fish_speech_amd/csrc/common.cpp -o tools/bin/gemv_bench && tools/bin/gemv_bench
 // Every launch streams a different weight copy (round-robin over ~2 GB: no cache reuse).  GEMV_CHECK=1 also compares
-// every row of the M = 8 / 16 results with the M = 1 result of that row (batch invariance, bit for bit).
+// every row of the M = 8 ... 32 results with the M = 1 result of that row (batch invariance, bit for bit).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -91,32 +91,32 @@ int main() {
     hipFree(rowmajor);
     const int n_out = sh.epi == EPI_SILU ? sh.N / 2 : sh.N;
     bf16_t *x, *nw, *res, *out, *out1;
-    CK(hipMalloc((void**)&x, (size_t)16 * sh.K * 2)); CK(hipMalloc((void**)&nw, (size_t)sh.K * 2));
-    CK(hipMalloc((void**)&res, (size_t)16 * n_out * 2)); CK(hipMalloc((void**)&out, (size_t)16 * n_out * 2)); CK(hipMalloc((void**)&out1, (size_t)16 * n_out * 2));
-    hipLaunchKernelGGL(fill_kernel, dim3((16 * sh.K + 255) / 256), dim3(256), 0, 0, x, (size_t)16 * sh.K, 11u, 1.0f);
+    CK(hipMalloc((void**)&x, (size_t)32 * sh.K * 2)); CK(hipMalloc((void**)&nw, (size_t)sh.K * 2));
+    CK(hipMalloc((void**)&res, (size_t)32 * n_out * 2)); CK(hipMalloc((void**)&out, (size_t)32 * n_out * 2)); CK(hipMalloc((void**)&out1, (size_t)32 * n_out * 2));
+    hipLaunchKernelGGL(fill_kernel, dim3((32 * sh.K + 255) / 256), dim3(256), 0, 0, x, (size_t)32 * sh.K, 11u, 1.0f);
     hipLaunchKernelGGL(fill_kernel, dim3((sh.K + 255) / 256), dim3(256), 0, 0, nw, (size_t)sh.K, 13u, 1.0f);
-    hipLaunchKernelGGL(fill_kernel, dim3((16 * n_out + 255) / 256), dim3(256), 0, 0, res, (size_t)16 * n_out, 17u, 1.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3((32 * n_out + 255) / 256), dim3(256), 0, 0, res, (size_t)32 * n_out, 17u, 1.0f);
     printf("%s  (%.1f MB%s)\n", sh.name, bytes / 1e6, rows ? ", row-balanced copy" : "");
     LinearArgs a{};
     a.x = x; a.ldx = sh.K; a.norm_w = sh.norm ? nw : nullptr; a.eps = 1e-6f; a.res = res; a.N = sh.N; a.K = sh.K; a.epi = sh.epi;
     a.ldr = n_out; a.out = out; a.ldo = n_out;
-    for (int M : {1, 8, 12, 16}) {
+    for (int M : {1, 8, 12, 16, 24, 32}) {
       a.M = M;
       const float us = time_launches(a, w16, wr, iters);
       printf("  M=%2d shipped launcher : %7.2f us  %6.0f GB/s\n", M, us, bytes / us * 1e-3);
       fflush(stdout);
     }
     if (check) {  // row r of the M-row result == the M = 1 result of that row
-      std::vector<bf16_t> ref((size_t)16 * n_out), got((size_t)16 * n_out);
-      for (int r = 0; r < 16; ++r) {
+      std::vector<bf16_t> ref((size_t)32 * n_out), got((size_t)32 * n_out);
+      for (int r = 0; r < 32; ++r) {
         LinearArgs b = a; b.M = 1; b.x = x + (size_t)r * sh.K; b.res = res + (size_t)r * n_out; b.out = out1 + (size_t)r * n_out;
         b.wp = w16[0]; b.wr = rows ? wr[0] : nullptr;
         launch_linear_skinny(b, 0);
       }
       CK(hipMemcpy(ref.data(), out1, ref.size() * 2, hipMemcpyDeviceToHost));
-      for (int M : {8, 12, 16}) {
+      for (int M : {8, 12, 16, 17, 24, 32}) {
         LinearArgs b = a; b.M = M; b.wp = w16[0]; b.wr = rows ? wr[0] : nullptr;
-        CK(hipMemset(out, 0, (size_t)16 * n_out * 2));
+        CK(hipMemset(out, 0, (size_t)32 * n_out * 2));
         launch_linear_skinny(b, 0);
         CK(hipMemcpy(got.data(), out, got.size() * 2, hipMemcpyDeviceToHost));
         const bool same = memcmp(ref.data(), got.data(), (size_t)M * n_out * 2) == 0;
