@@ -379,14 +379,15 @@ constexpr int SKINNY_XH = 5;   // k-tile pairs of activations a wave can hold (K
 
 // UNR = k-tile pairs in flight per wave; TILES = 16-row weight tiles per work-group (SwiGLU: gate/up tiles
 // alternate, so TILES is even).
-// XR = activation rows the launch can take: 8 (M <= 8: ONE all-lanes load of eight full cache lines is the B operand of
-// both k-tiles of a pair -- rows in columns 0-7 for tile 0, 8-15 for tile 1, half of every product is padding), or 16 / 32
-// (round 6, the NATIVE form: a column set = 16 activation rows in the 16 MFMA columns, one 16-byte load per lane and
-// k-tile, every column of every product is a row's; XR = 32 = two column sets with their own accumulators).  Round 4's
-// 16-row form was two 8-row sets (twice the MFMAs and accumulators of the 8-row form: w1|w3 25.7 us at M = 16 against
-// 20.4 at M = 8); the native form costs what the 8-row form costs.  In every form a row sees the same products in the same
-// order -- k-tile 0 / k-tile 1 of every pair in two accumulators that meet once at the end -- and its RMSNorm statistics
-// the same partition and tree, so its result does not depend on the batch it is in or on the form the row count selects.
+// XR = activation rows the launch can take, in sets of 8: 8 (M <= 8: one all-lanes load of eight full cache lines per
+// pair), 16 (M <= 16, round 4: a second load brings rows 8-15; tile 0 / tile 1 of the pair then accumulate rows 8-15 in a
+// second accumulator pair, columns 0-7 / 8-15 again) or 32 (round 6: four sets -- the merged fast positions 0/1 of a
+// batch of 9-16).  A row's products and their order are the same in every form and the same whichever load the row
+// arrives in, so its result does not depend on the batch it is in.
+// (Round 6 also built the "native" 16-row form -- 16 activation rows in the 16 MFMA columns, half the products and
+// accumulators of two 8-row sets, bit-identical -- and measured it SLOWER: w1|w3 at M = 16 30.5 us against 25.7, because
+// its two loads per pair touch 16 half lines each where a set's load touches 8 full lines; the GEMV is bound by cache-line
+// requests in flight per CU, not by products.  profiles/r06_gemv_native16.txt.)
 // Q8: the weights are the int8 tiles of a weight-only-int8 checkpoint (a.wq, launch_pack_weight_int8): one 16-byte
 // load per lane brings both k-tiles of a pair, converted to bf16 in registers (exact: |v| <= 128) right before the
 // same MFMAs -- the products, their order and hence the result bits equal the bf16 kernel on the dequantised
@@ -416,15 +417,12 @@ template <int WAVES, int EPI, bool NORM, int UNR, int TILES, int XR, bool NT = t
 __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR == 1) ? (((XR == 8 || XH == 0) && XR != 32) ? 6 : 4) : 1) void linear_skinny_kernel(LinearArgs a) {
   static_assert(KSL == 1 || (!NORM && !Q8 && XR == 8), "k-slices: plain bf16 linears of up to 8 rows");
   static_assert(EPI != EPI_SILU || TILES % 2 == 0, "SwiGLU needs gate/up tile pairs");
-  static_assert(XR == 8 || XR == 16 || XR == 32, "8 rows, or column sets of 16");
-  static_assert(!(Q8 && XR != 8), "int8 tiles: the 8-row form only");
+  static_assert(XR == 8 || XR == 16 || XR == 32, "activation row sets of 8");
+  static_assert(!(Q8 && XR != 8), "int8 tiles: one row set");
   static_assert(ROWS >= 1 && ROWS <= 16 && (ROWS == 16 || (!Q8 && EPI != EPI_SILU)), "row-balanced tiles: bf16, no SwiGLU");
   static_assert(XH == 0 || NORM, "held activation fragments belong to the norm-fused variants");
-  constexpr bool NAT = XR >= 16;            // native form: 16 activation rows per column set
-  constexpr int CS = NAT ? XR / 16 : 1;     // column sets
-  constexpr int XS = NAT ? 2 * CS : 1;      // activation registers (16-byte loads) per k-tile pair: [2 cs + k-tile] / the one
-  constexpr int NACC = 2 * CS;              // accumulators per weight tile: [2 cs + k-tile of the pair]
-  constexpr int RS = NAT ? 16 : 8;          // rows per set
+  constexpr int XS = XR / 8;          // all-lanes activation loads per k-tile pair
+  constexpr int CS = XS > 1 ? XS / 2 : 1;   // 16-column groups of results: row sets 2 cs, 2 cs + 1
   constexpr int XHN = XH > 0 ? XH : 1;
   constexpr int TSTRIDE = ROWS * 4;   // u32x4 per (tile, k-tile): ROWS rows x 4 lane groups
   __shared__ float red[WAVES][TILES][CS * 256];
@@ -451,20 +449,14 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     return reinterpret_cast<const u32x4*>(wbase + unit * 16 + wlane);
   };
 
-  // activation fragment addressing.  8-row form: fetch lane = kt*32 + g'*8 + row -> x[row][64 p + 32 kt + 8 g' ..]; as
-  // MFMA B operand that register is column (g'&1)*8 + row, lane group kt*2 + (g'>>1) (see packed_k0): the "k-tiles" of a
-  // pair are its even / odd 8-element chunks.  Native form, register 2 cs + h: lane (q = lane >> 4, row = lane & 15) ->
-  // x[16 cs + row][64 p + 16 q + 8 h ..] = chunk 2 q + h: column `row`, lane group q of k-tile h -- the same chunk in the
-  // same lane group as in the 8-row form.  k_off = the chunk's element offset inside the pair (norm weights use it too).
+  // activation fragment addressing: fetch lane = kt*32 + g'*8 + row -> x[8 s + row][64 p + 32 kt + 8 g' ..] for row
+  // set s; as MFMA B operand that register is column (g'&1)*8 + row, lane group kt*2 + (g'>>1) (see packed_k0)
+  const int f_off = (lane >> 5) * 32 + ((lane >> 3) & 3) * 8;
   const char* __restrict__ xbase = reinterpret_cast<const char*>(a.x);
-  uint32_t xoff[XS], k_off[XS];
+  uint32_t xoff[XS];
 #pragma unroll
-  for (int i = 0; i < XS; ++i) {
-    k_off[i] = NAT ? (uint32_t)((lane >> 4) * 16 + (i & 1) * 8) : (uint32_t)((lane >> 5) * 32 + ((lane >> 3) & 3) * 8);
-    const int row = NAT ? (i >> 1) * 16 + (lane & 15) : (lane & 7);
-    xoff[i] = (uint32_t)(min(row, a.M - 1) * a.ldx + (int)k_off[i]) * 2u;
-  }
-  auto xptr = [&](int i, int p) -> const uint4* { return reinterpret_cast<const uint4*>(xbase + (int64_t)p * 128 + xoff[i]); };
+  for (int s = 0; s < XS; ++s) xoff[s] = (uint32_t)(min(s * 8 + (lane & 7), a.M - 1) * a.ldx + f_off) * 2u;
+  auto xptr = [&](int s, int p) -> const uint4* { return reinterpret_cast<const uint4*>(xbase + (int64_t)p * 128 + xoff[s]); };
   const char* __restrict__ nbase = reinterpret_cast<const char*>(a.norm_w);
 
   // XH > 0: the norm weight vector (K / 8 = XH * WAVES * 8 <= WAVES * 64 chunks: one per thread) is requested FIRST, so
@@ -555,37 +547,9 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     }
   };
 
-  // sum of squares of one held / fetched register: the lane's chunk, sequentially over its pairs and elements
-  auto sumsq = [](const auto& regs, float ss) -> float {   // (regs: uint4[n], n a compile-time constant: stays in registers)
-    constexpr int n = (int)(sizeof(regs) / sizeof(uint4));
+  float rstd[XS];
 #pragma unroll
-    for (int u = 0; u < n; ++u) {
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&regs[u]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float f = bf2f(e[j]);
-        ss = fmaf(f, f, ss);
-      }
-    }
-    return ss;
-  };
-  // ... then the eight chunks of the row by the tree (c ^ 1, c ^ 2, c ^ 4): three xor steps over the chunk lanes in the
-  // 8-row form; in the native form the lane's own two chunks (2 q, 2 q + 1) meet first, then lanes q ^ 1, q ^ 2
-  auto chunk_tree = [&](float ss0, float ss1) -> float {
-    float ss;
-    if (NAT) {
-      ss = ss0 + ss1;
-    } else {
-      ss = ss0;
-      ss += __shfl_xor(ss, 8, 64);
-    }
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    return ss;
-  };
-  float rstd[CS];
-#pragma unroll
-  for (int cs = 0; cs < CS; ++cs) rstd[cs] = 0.f;
+  for (int s = 0; s < XS; ++s) rstd[s] = 0.f;
   if (NORM && XH > 0) {
     // the norm weights travel through LDS (one 16-byte load per thread -- requested at the top of the kernel --, read
     // back as broadcasts after the statistics barrier): held in registers next to the fragments they cost the w1|w3
@@ -593,27 +557,37 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     // sum of squares: lane (chunk c = lane >> 3, row) sequentially over its pairs and elements, then the eight chunk
     // lanes of the row by an xor tree (c bit 0, 1, 2), then the waves in order
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) {
-      const float ss = chunk_tree(sumsq(xh[NAT ? 2 * cs : 0], 0.f), NAT ? sumsq(xh[NAT ? 2 * cs + 1 : 0], 0.f) : 0.f);
-      if (lane < RS) s_part[wave][cs * RS + lane] = ss;
+    for (int s = 0; s < XS; ++s) {
+      float ss = 0.f;
+#pragma unroll
+      for (int u = 0; u < XHN; ++u) {
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&xh[s][u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = bf2f(e[j]);
+          ss = fmaf(f, f, ss);
+        }
+      }
+      ss += __shfl_xor(ss, 8, 64);
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lane < 8) s_part[wave][s * 8 + lane] = ss;
     }
     if (nw_has && a.late_epi == 2) nw_stage = reinterpret_cast<const uint4*>(a.norm_w)[tid];   // where round 4 began: behind the weight requests
     if (nw_has) s_nw[tid] = nw_stage;
     __syncthreads();
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) {
+    for (int s = 0; s < XS; ++s) {
       float tot = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) tot += s_part[w][cs * RS + (lane & (RS - 1))];
-      rstd[cs] = rsqrtf(tot / (float)a.K + a.eps);
-    }
-#pragma unroll
-    for (int i = 0; i < XS; ++i)
+      for (int w = 0; w < WAVES; ++w) tot += s_part[w][s * 8 + (lane & 7)];
+      rstd[s] = rsqrtf(tot / (float)a.K + a.eps);
 #pragma unroll
       for (int u = 0; u < XHN; ++u) {
-        const bf16x8 nf = norm_frag(xh[i][u], s_nw[(pbeg + u) * 8 + (k_off[i] >> 3)], rstd[NAT ? i >> 1 : 0]);
-        xh[i][u] = *reinterpret_cast<const uint4*>(&nf);
+        const bf16x8 nf = norm_frag(xh[s][u], s_nw[(pbeg + u) * 8 + (lane >> 3)], rstd[s]);
+        xh[s][u] = *reinterpret_cast<const uint4*>(&nf);
       }
+    }
   } else if (NORM && (a.K & 63) == 0 && (a.K >> 6) == SKINNY_XH * WAVES) {
     // A shape the held-fragment variants (XH > 0) also serve, e.g. the 9-16-row SwiGLU form next to the <= 8-row one:
     // the statistics take THEIR partition and reduction tree -- wave w over its own k-slice, lane (chunk, row)
@@ -622,22 +596,32 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     // (row_rstd's lane-strided sum + wave_sum is another fp32 order).  The fragments are not held: they are
     // re-read (L2 hits) by the product loop below.
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) {
-      uint4 xt[NAT ? 2 : 1][SKINNY_XH];
+    for (int s = 0; s < XS; ++s) {
+      uint4 xt[SKINNY_XH];
 #pragma unroll
-      for (int h = 0; h < (NAT ? 2 : 1); ++h)
+      for (int u = 0; u < SKINNY_XH; ++u) xt[u] = *xptr(s, pbeg + u);
+      float ss = 0.f;
 #pragma unroll
-        for (int u = 0; u < SKINNY_XH; ++u) xt[h][u] = *xptr(NAT ? 2 * cs + h : 0, pbeg + u);
-      const float ss = chunk_tree(sumsq(xt[0], 0.f), NAT ? sumsq(xt[NAT ? 1 : 0], 0.f) : 0.f);
-      if (lane < RS) s_part[wave][cs * RS + lane] = ss;
+      for (int u = 0; u < SKINNY_XH; ++u) {
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&xt[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = bf2f(e[j]);
+          ss = fmaf(f, f, ss);
+        }
+      }
+      ss += __shfl_xor(ss, 8, 64);
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lane < 8) s_part[wave][s * 8 + lane] = ss;
     }
     __syncthreads();
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) {
+    for (int s = 0; s < XS; ++s) {
       float tot = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) tot += s_part[w][cs * RS + (lane & (RS - 1))];
-      rstd[cs] = rsqrtf(tot / (float)a.K + a.eps);
+      for (int w = 0; w < WAVES; ++w) tot += s_part[w][s * 8 + (lane & 7)];
+      rstd[s] = rsqrtf(tot / (float)a.K + a.eps);
     }
   } else if (NORM) {
     for (int r = wave; r < a.M; r += WAVES) {
@@ -646,32 +630,33 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
     }
     __syncthreads();
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) rstd[cs] = s_rstd[min(cs * RS + (lane & (RS - 1)), a.M - 1)];
+    for (int s = 0; s < XS; ++s) rstd[s] = s_rstd[min(s * 8 + (lane & 7), a.M - 1)];
   }
 
-  // [2 cs + k-tile of the pair]: 8-row form valid in columns 0-7 (k-tile 0) / 8-15 (k-tile 1); native: all 16 columns
-  f32x4 acc[NACC][TILES];
+  f32x4 acc[2 * XS][TILES];   // [2 s + tile-of-pair]: row set s, valid in columns 0-7 (tile 0) / 8-15 (tile 1)
 #pragma unroll
-  for (int i = 0; i < NACC; ++i)
+  for (int i = 0; i < 2 * XS; ++i)
 #pragma unroll
     for (int t = 0; t < TILES; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto frag = [&](int i, int p) -> bf16x8 {  // activation (optionally normalised) register i of k-tile pair p
-    uint4 xv = *xptr(i, p);
+  auto frag = [&](int s, int p) -> bf16x8 {  // activation (optionally normalised) fragment of k-tile pair p
+    uint4 xv = *xptr(s, p);
     if (NORM) {
-      uint4 nv = *reinterpret_cast<const uint4*>(nbase + (int64_t)p * 128 + k_off[i] * 2u);
-      return norm_frag(xv, nv, rstd[NAT ? i >> 1 : 0]);
+      uint4 nv = *reinterpret_cast<const uint4*>(nbase + (int64_t)p * 128 + (uint32_t)f_off * 2u);
+      return norm_frag(xv, nv, rstd[s]);
     }
     return *reinterpret_cast<bf16x8*>(&xv);
   };
   auto mma_pair = [&](int slot, const bf16x8* xs) {   // one k-tile pair: weights of ring slot `slot`, fragments xs[XS]
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      u32x4 w[2] = {wa[t][slot][0], wa[t][slot][1]};
-      if (Q8) unpack_q8(wa[t][slot][0], w[0], w[1]);
+      u32x4 w0 = wa[t][slot][0], w1 = wa[t][slot][1];
+      if (Q8) unpack_q8(wa[t][slot][0], w0, w1);
 #pragma unroll
-      for (int i = 0; i < NACC; ++i)
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w[i & 1]), xs[NAT ? i : 0], acc[i][t], 0, 0, 0);
+      for (int s = 0; s < XS; ++s) {
+        acc[2 * s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xs[s], acc[2 * s][t], 0, 0, 0);
+        acc[2 * s + 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xs[s], acc[2 * s + 1][t], 0, 0, 0);
+      }
     }
   };
 
@@ -688,18 +673,19 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
           u32x4 w0, w1;
           unpack_q8(wa[t][slot][0], w0, w1);
           if (more) wa[t][slot][0] = wload<NT>(wptr(t, pbeg + u + UNR));
-          {   // (int8: the 8-row form only)
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&xh[0][u]);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xv, acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xv, acc[1][t], 0, 0, 0);
+#pragma unroll
+          for (int s = 0; s < XS; ++s) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&xh[s][u]);
+            acc[2 * s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w0), xv, acc[2 * s][t], 0, 0, 0);
+            acc[2 * s + 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w1), xv, acc[2 * s + 1][t], 0, 0, 0);
           }
         } else {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int cs = 0; cs < CS; ++cs)
-              acc[2 * cs + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][slot][h]),
-                                                                            *reinterpret_cast<const bf16x8*>(&xh[NAT ? 2 * cs + h : 0][u]), acc[2 * cs + h][t], 0, 0, 0);
+            for (int s = 0; s < XS; ++s)
+              acc[2 * s + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wa[t][slot][h]),
+                                                                           *reinterpret_cast<const bf16x8*>(&xh[s][u]), acc[2 * s + h][t], 0, 0, 0);
             if (more) wa[t][slot][h] = wload<NT>(wptr(t, 2 * (pbeg + u + UNR) + h));
           }
         }
@@ -747,17 +733,21 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
         if (p + u < pend) mma_pair(u, xs[u]);
     }
   }
-  // fold: the sums over k-tile 0 and k-tile 1 of the pairs meet -- 8-row form: tile 1's sit in columns 8-15 of the same
-  // rows; native: same columns -- and land in acc[2 cs], column = activation row (mod 16)
+  // fold: tile 1's sums sit in columns 8-15 of the same rows; of every two row sets the second (rows 8-15 of the group of 16)
+  // moves to columns 8-15: acc[4 cs] then holds activation rows 16 cs .. 16 cs + 15 in its 16 columns
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (NAT) {
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs) acc[2 * cs][t][j] = acc[2 * cs][t][j] + acc[2 * cs + 1][t][j];
-      } else {
-        acc[0][t][j] = acc[0][t][j] + dpp_row_shl8(acc[1][t][j]);
+      for (int cs = 0; cs < CS; ++cs) {
+        float v = acc[4 * cs][t][j] + dpp_row_shl8(acc[4 * cs + 1][t][j]);
+        if (XS >= 2) {
+          const float v1 = acc[XS >= 2 ? 4 * cs + 2 : 0][t][j] + dpp_row_shl8(acc[XS >= 2 ? 4 * cs + 3 : 0][t][j]);
+          const float v1s = dpp_row_shr8(v1);   // every lane executes the DPP move (a disabled source lane reads as invalid)
+          v = (b < 8) ? v : v1s;
+        }
+        acc[4 * cs][t][j] = v;
       }
     }
   if (!Q8 && (KT & 1) && wave == WAVES - 1) {  // unpaired last k-tile (plain k order), after the fold: same in every variant
@@ -776,7 +766,7 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
         u32x4 wv = wload<NT>(wptr(t, kt));
-        acc[2 * cs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[2 * cs][t], 0, 0, 0);
+        acc[4 * cs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), xb, acc[4 * cs][t], 0, 0, 0);
       }
     }
   }
@@ -784,7 +774,7 @@ __global__ __launch_bounds__(WAVES * 64, (EPI == EPI_SILU && WAVES == 8 && UNR =
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) *reinterpret_cast<f32x4*>(&red[wave][t][cs * 256 + lane * 4]) = acc[2 * cs][t];
+    for (int cs = 0; cs < CS; ++cs) *reinterpret_cast<f32x4*>(&red[wave][t][cs * 256 + lane * 4]) = acc[4 * cs][t];
   __syncthreads();
 
   if constexpr (KSL > 1) {

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/bin
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result -I fish_speech_amd/csrc"
-ALL="sampler_bench gemv_bench gemv_ksplit_probe l2_prefetch_probe mall_probe mall_resident_probe gemm_bench overlap_bench runahead_bench persist_probe gemv_lds_probe gemv_q8_bench gemv_rows_bench"
+ALL="engine_probe sampler_bench gemv_bench gemv_ksplit_probe l2_prefetch_probe mall_probe mall_resident_probe gemm_bench overlap_bench runahead_bench persist_probe gemv_lds_probe gemv_q8_bench gemv_rows_bench"
 for t in ${*:-$ALL}; do
   src=tools/$t.hip
   [ -f "$src" ] || { echo "no such tool: $t"; continue; }
