@@ -89,6 +89,8 @@ struct fmi_dualar {
   std::vector<void*> row_copies;       // their allocations
   bool use_graph = true, ignore_eos = false;
   int trace = 0;   // fmi_dualar_set_trace: 0 off, 1 per-position fast logits kept + plain GEMV path, 2 kept on the frame loop's own path (table)
+  float* gemm_part = nullptr;        // partial tiles of the split-contraction prefill GEMM (linear_tiled_ksplit), grown on demand
+  int64_t gemm_part_floats = 0;
   bool skinny32 = false;             // linear(): rows 17-32 may take the decode GEMV (set by tail() around the merged fast pass)
   const int32_t* forced = nullptr;   // fmi_dualar_fast_chain_forced only: the frame that replaces the draws
   bool tail_in_normed = false;       //   "  : tail()'s input rows are already normed (the hidden the reference hands over)
@@ -330,6 +332,18 @@ int linear(fmi_dualar* h, const bf16_t* x, int ldx, const bf16_t* wp, const bf16
     h->launches += 1;
   }
   h->launches += 1;
+  if (const int64_t need = linear_tiled_part_floats(M, N, K); need > 0) {
+    if (h->gemm_part_floats < need) {
+      FMI_CHECK_HIP(hipStreamSynchronize(s));
+      if (h->gemm_part) hipFree(h->gemm_part);
+      h->gemm_part = nullptr;
+      h->gemm_part_floats = 0;
+      FMI_CHECK_HIP(hipMalloc((void**)&h->gemm_part, (size_t)need * 4));
+      h->gemm_part_floats = need;
+    }
+    a.part = h->gemm_part;
+    h->launches += 1;
+  }
   return launch_linear_tiled(a, s);
 }
 
@@ -687,7 +701,7 @@ void fmi_dualar_destroy(fmi_dualar* h) {
   void* ptrs[] = {h->st.pos, h->st.frame, h->st.done, h->st.limit, h->st.cur, h->st.window, h->st.out,
                   h->st.temperature, h->st.top_p, h->st.top_k, h->st.seed, h->st.use_ras, h->st.block_table,
                   h->hn, h->hf, h->xl, h->xf, h->logits, h->flogits, h->ftrace, h->staging, h->staging2,
-                  h->qkv0_tab, h->qkv0_pre, h->attn_part, h->hfp, h->x01};
+                  h->qkv0_tab, h->qkv0_pre, h->attn_part, h->hfp, h->x01, h->gemm_part};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (void* p : h->row_copies) hipFree(p);
@@ -1504,7 +1518,14 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
         a.x = xn;
         a.norm_w = nullptr;
       }
+      float* part = nullptr;   // (the shape may run with a split contraction: linear_tiled_ksplit)
+      if (rc == FMI_OK && force_path == 2 && linear_tiled_part_floats(M, N, K) > 0) {
+        if (hipMalloc((void**)&part, (size_t)linear_tiled_part_floats(M, N, K) * 4) != hipSuccess) rc = set_error(FMI_EHIP, "hipMalloc");
+        a.part = part;
+      }
       if (rc == FMI_OK) rc = launch_linear_tiled(a, s, force_path == 5, force_path == 7 ? 1 : force_path == 8 ? 2 : force_path == 9 ? 3 : force_path == 10 ? 7 : force_path == 11 ? 10 : force_path == 12 ? 9 : force_path == 13 ? 4 : force_path == 14 ? 11 : force_path == 15 ? 12 : 0);
+      hipStreamSynchronize(s);
+      if (part) hipFree(part);
     }
   }
   hipStreamSynchronize(s);

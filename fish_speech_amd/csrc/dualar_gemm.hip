@@ -672,16 +672,20 @@ __global__ __launch_bounds__(512, 2) void linear_tiled_256p_kernel(LinearArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 3, wm = wave >> 2;
-  const int KT = a.K >> 5, KS = KT >> 1;
+  const int KT = a.K >> 5;
+  // gridDim.z > 1 (linear_tiled_ksplit): this work-group takes k-steps [ks0, ks0 + KS) of the KT / 2 and leaves its
+  // accumulators as an fp32 partial tile; the sources below start at ks0, the loop itself is unchanged
+  const int ks0 = (int)(((int64_t)(KT >> 1) * blockIdx.z) / gridDim.z);
+  const int KS = (int)(((int64_t)(KT >> 1) * (blockIdx.z + 1)) / gridDim.z) - ks0;
   const int NT = a.N >> 4;
   const int n_blk0 = blockIdx.x * 16, m_blk0 = blockIdx.y * BM;
   const int mi = lane & 15, g = lane >> 4;
 
   // DMA sources: wave-uniform 64-bit bases + 32-bit per-lane offsets
-  const char* wb0 = reinterpret_cast<const char*>(a.wp) + ((int64_t)min(n_blk0 + 2 * wave, NT - 1) * KT) * 1024;
-  const char* wb1 = reinterpret_cast<const char*>(a.wp) + ((int64_t)min(n_blk0 + 2 * wave + 1, NT - 1) * KT) * 1024;
+  const char* wb0 = reinterpret_cast<const char*>(a.wp) + ((int64_t)min(n_blk0 + 2 * wave, NT - 1) * KT) * 1024 + (int64_t)ks0 * 2048;
+  const char* wb1 = reinterpret_cast<const char*>(a.wp) + ((int64_t)min(n_blk0 + 2 * wave + 1, NT - 1) * KT) * 1024 + (int64_t)ks0 * 2048;
   const uint32_t woff = (uint32_t)lane * 16u;
-  const char* xb = reinterpret_cast<const char*>(a.x);
+  const char* xb = reinterpret_cast<const char*>(a.x) + (int64_t)ks0 * 128;
   uint32_t xoff[XPW];
   {
     const int r = lane >> 3, c = lane & 7;
@@ -818,11 +822,51 @@ __global__ __launch_bounds__(512, 2) void linear_tiled_256p_kernel(LinearArgs a)
   mma_set(wB, xB, false, 0, false, 0);
 #undef FMI_WAIT_SET
   FMI_YSTAMP(2);
+  if (gridDim.z > 1) {   // partial tile in fragment order: 1 KiB per store instruction (linear_tiled_reduce_kernel reads it back the same way)
+    f32x4* dst = reinterpret_cast<f32x4*>(a.part) +
+                 ((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * (4 * MF * 64) + lane;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int f = 0; f < MF; ++f) dst[(tn * MF + f) * 64] = acc[tn][f];
+    return;
+  }
   epilogue_256<EPI, MF>(a, acc, lds0, wave, wn, wm, n_blk0, m_blk0, lane);
 #if defined(FMI_Y_TIMING)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   FMI_YSTAMP(3);
 #endif
+}
+
+// Second launch of a split contraction (linear_tiled_ksplit): same grid (x, y) and wave / lane roles as the
+// linear_tiled_256p_kernel<EPI, false, MF> launch whose gridDim.z = S work-groups per tile left their accumulators in
+// a.part; the S partial tiles are added in range order (fixed: the bits do not depend on who finished first) and the
+// ordinary epilogue runs on the sums.
+template <int EPI, int MF>
+__global__ __launch_bounds__(512, 2) void linear_tiled_reduce_kernel(LinearArgs a, int S) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+  const int n_blk0 = blockIdx.x * 16, m_blk0 = blockIdx.y * (32 * MF);
+  const int64_t zstride = (int64_t)gridDim.y * gridDim.x * 8 * (4 * MF * 64);
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.part) + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * (4 * MF * 64) + lane;
+  f32x4 acc[4][MF];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int f = 0; f < MF; ++f) acc[tn][f] = __builtin_nontemporal_load(src + (tn * MF + f) * 64);
+  for (int z = 1; z < S; ++z) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        const f32x4 v = __builtin_nontemporal_load(src + z * zstride + (tn * MF + f) * 64);
+        acc[tn][f] = acc[tn][f] + v;
+      }
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  epilogue_256<EPI, MF>(a, acc, lds0, wave, wn, wm, n_blk0, m_blk0, lane);
 }
 
 // linear_tiled_256w16_kernel: the 256 x 256 tile on SIXTEEN waves (4 x 4, each 64 rows x 64 columns, <= 128 registers:
@@ -928,8 +972,60 @@ __global__ __launch_bounds__(1024, 4) void linear_tiled_256w16_kernel(LinearArgs
 #endif
 }
 
+int linear_tiled_ksplit(int N, int K) {
+  static const bool off = []() { const char* e = getenv("FMI_GEMM_NOSPLIT"); return e && atoi(e) != 0; }();   // (A/B runs)
+  // w2 of the S2-Pro shape (2560 x 9728).  At 8 x 200 rows: 250 work-groups of 64 rows x 256 columns, each bound by the
+  // ~50 GB/s a CU takes operands in at -> 128 us; 210 work-groups of 256 x 256 over a third of K each move 0.52 of the
+  // bytes per CU.  wo (K = 4096) does not pay: what the split saves the partial tiles cost again.
+  if (off || N % 16 != 0 || N < 1024 || N > 2560 || K < 8192 || ((K >> 5) & 1)) return 1;
+  return 3;
+}
+
+static int ksplit_mf(int M, int N, int S) {   // the smallest tile (least operand bytes per work-group) that still fits one round
+  const int ct = cdiv(N, 256);
+  for (int mf = 2; mf <= 8; mf += 2)
+    if (ct * cdiv(M, 32 * mf) * S <= 256) return mf;
+  return 8;
+}
+
+int64_t linear_tiled_part_floats(int M, int N, int K) {
+  const int S = linear_tiled_ksplit(N, K);
+  if (S <= 1) return 0;
+  const int mf = ksplit_mf(M, N, S);
+  return (int64_t)S * cdiv(M, 32 * mf) * cdiv(N, 256) * 8 * (4 * mf * 64) * 4;
+}
+
 int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct, int variant) {
   FMI_REQUIRE(a.norm_w == nullptr, "linear_tiled: fused norm not supported (use rmsnorm_rows)");
+  if (const int S = linear_tiled_ksplit(a.N, a.K); S > 1 && !force_direct && variant == 0) {
+    FMI_REQUIRE(a.part != nullptr, "linear_tiled: this shape runs with a split contraction and needs LinearArgs::part");
+    FMI_REQUIRE(a.bias == nullptr && a.ldx % 8 == 0 && a.ldo % 8 == 0 && (a.epi != EPI_RESIDUAL || a.ldr % 8 == 0) && a.N % 8 == 0,
+                "linear_tiled: bad shape for the split contraction");
+    const int mf = ksplit_mf(a.M, a.N, S);
+#define FMI_LAUNCH_SPLIT(EPI_, MF_, SMEM_)                                                                                     \
+    do {                                                                                                                      \
+      static const hipError_t e0 = hipFuncSetAttribute((const void*)linear_tiled_256p_kernel<EPI_, false, MF_>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_); \
+      static const hipError_t e1 = hipFuncSetAttribute((const void*)linear_tiled_reduce_kernel<EPI_, MF_>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_ * 16384); \
+      FMI_CHECK_HIP(e0); FMI_CHECK_HIP(e1);                                                                                   \
+      const dim3 g3(cdiv(a.N / 16, 16), cdiv(a.M, 32 * MF_), S), g2(g3.x, g3.y);                                              \
+      hipLaunchKernelGGL((linear_tiled_256p_kernel<EPI_, false, MF_>), g3, dim3(512), SMEM_, s, a);                            \
+      hipLaunchKernelGGL((linear_tiled_reduce_kernel<EPI_, MF_>), g2, dim3(512), MF_ * 16384, s, a, S);                        \
+    } while (0)
+#define FMI_LAUNCH_SPLIT_MF(EPI_)                                   \
+    do {                                                           \
+      if (mf == 2) FMI_LAUNCH_SPLIT(EPI_, 2, 81920);               \
+      else if (mf == 4) FMI_LAUNCH_SPLIT(EPI_, 4, 98304);          \
+      else if (mf == 6) FMI_LAUNCH_SPLIT(EPI_, 6, 114688);         \
+      else FMI_LAUNCH_SPLIT(EPI_, 8, 131072);                      \
+    } while (0)
+    if (a.epi == EPI_STORE) FMI_LAUNCH_SPLIT_MF(EPI_STORE);
+    else if (a.epi == EPI_RESIDUAL) FMI_LAUNCH_SPLIT_MF(EPI_RESIDUAL);
+    else FMI_LAUNCH_SPLIT_MF(EPI_SILU);
+#undef FMI_LAUNCH_SPLIT_MF
+#undef FMI_LAUNCH_SPLIT
+    FMI_CHECK_HIP(hipGetLastError());
+    return FMI_OK;
+  }
   FMI_REQUIRE(a.bias == nullptr, "linear_tiled: no bias epilogue (skinny kernel only)");
   FMI_REQUIRE(a.K % 32 == 0 && a.N % 16 == 0 && a.ldx % 8 == 0 && a.ldo % 4 == 0, "linear_tiled: bad shape");
   if (a.epi == EPI_SILU) FMI_REQUIRE(a.N % 32 == 0, "linear_tiled: SwiGLU needs N %% 32");

@@ -71,6 +71,7 @@ struct LinearArgs {
   // tools/gemv_ksplit_probe.hip only (linear_skinny_kernel<..., KSL > 1>: the K range split over gridDim.y work-groups
   // per row block -- fewer activation requests per weight byte -- with a fixed-order cross-work-group reduction):
   float* part;             // [gridDim.y][gridDim.x][TILES][256] fp32 partial sums
+                           // (launch_linear_tiled with linear_tiled_ksplit(N, K) > 1: its partial tiles, linear_tiled_part_floats)
   unsigned* cnt;           // [gridDim.x] arrival counters (zero between launches); nullptr = partials only (upper bound)
   int part_proto;          // 0: partials by plain stores + agent-scope release / acquire fences; 1: partials by agent-scope
                            //    (write-through / L2-bypassing) relaxed atomic stores and loads, no cache-wide fence
@@ -93,6 +94,13 @@ int launch_repack_rows(const bf16_t* packed16, bf16_t* dst, int N, int K, int ep
 // any M, no fused norm.  variant: 0 = default (FMI_GEMM env: d / l / w, else the built-in default), 1 = LDS-staged
 // 4-wave kernel, 2 = LDS-staged wave-specialised kernel; force_direct: operands straight from L2.  All bit-identical.
 int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct = false, int variant = 0);
+// Fixed split of the contraction (round 6) for the prefill GEMMs whose 256-column tiling leaves most CUs idle at a few
+// hundred to a few thousand rows (N <= 2560: ten column tiles) and whose K is long enough to pay for a reduce pass (w2:
+// K = 9728): S work-groups per output tile, each over 1 / S of the k-steps, fp32 partial tiles in LinearArgs::part, summed
+// in range order by a second launch that also runs the epilogue.  S depends on (N, K) ONLY -- never on M -- so a row's
+// bits do not depend on the rows it travels with (prefix reuse, ragged prefill).  1 = no split.
+int linear_tiled_ksplit(int N, int K);
+int64_t linear_tiled_part_floats(int M, int N, int K);   // floats LinearArgs::part must hold for a call (0: no split)
 int launch_rmsnorm_rows(const bf16_t* x, int ldx, const bf16_t* w, float eps, bf16_t* out, int ldo,
                         int M, int K, hipStream_t s, bf16_t* out2 = nullptr);
 

@@ -156,7 +156,17 @@ def test_lds_staged_prefill_gemm_equals_the_direct_variant(lib, M, N, K, epi):
     for path in (10, 11, 12, 13, 14, 15):
         y = _linear(lib, x, w, None, res, M, N, K, epi, path)
         assert torch.equal(y, direct), (path, float((y.float() - direct.float()).abs().max()))
-    assert torch.equal(_linear(lib, x, w, None, res, M, N, K, epi, 2), direct)   # whichever the shape selects
+    picked = _linear(lib, x, w, None, res, M, N, K, epi, 2)   # whichever the shape selects
+    if N <= 2560 and K >= 8192:
+        # round 6: w2's shape runs with the contraction split in three (linear_tiled_ksplit: by (N, K) only, so that a
+        # row's bits never depend on the rows it travels with) -- another fp32 summation order than the variants above:
+        # within the oracle's tolerance, and the first rows of this call equal a call of those rows alone, bit for bit
+        ok, mx, nbad = bf16_close(picked, _linear_oracle(x, w, None, res, epi), scale=res)
+        assert ok, (mx, nbad)
+        few = _linear(lib, x[:17].contiguous(), w, None, res[:17].contiguous() if res is not None else None, 17, N, K, epi, 2)
+        assert torch.equal(few, picked[:17]), "split contraction: a row's bits depend on the row count of the call"
+    else:
+        assert torch.equal(picked, direct)
     if M <= 300:
         ok, mx, nbad = bf16_close(staged, _linear_oracle(x, w, None, res, epi), scale=res)
         assert ok, (mx, nbad)
