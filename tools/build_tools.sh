@@ -13,7 +13,9 @@ for t in ${*:-$ALL}; do
   [ -f "$src" ] || { echo "no such tool: $t"; continue; }
   echo "hipcc $src"
   # (tools that include a kernel translation unit of the library need its host helpers: common.cpp)
-  if grep -q 'include "../fish_speech_amd/csrc' "$src"; then
+  if [ "$t" = gemm_bench ]; then   # includes dualar_gemm.hip; the weight packers live in dualar_kernels.hip
+    $HIPCC $FLAGS "$src" fish_speech_amd/csrc/dualar_kernels.hip fish_speech_amd/csrc/common.cpp -o tools/bin/$t 2>&1 | grep -E "error" || true
+  elif grep -q 'include "../fish_speech_amd/csrc' "$src"; then
     $HIPCC $FLAGS "$src" fish_speech_amd/csrc/common.cpp -o tools/bin/$t 2>&1 | grep -E "error" || true
   else
     $HIPCC $FLAGS "$src" -o tools/bin/$t 2>&1 | grep -E "error" || true

@@ -71,7 +71,7 @@ want stream && python tools/stream_breakdown.py > "$OUT/${TAG}_stream_breakdown.
 want stream && python tools/stream_latency.py > "$OUT/${TAG}_stream_latency.txt" 2>&1
 # prefill GEMM variants per shape (tools/gemm_bench.hip; the binary is built on the authoring side: see the file's header)
 if want gemm && [ -x tools/bin/gemm_bench ]; then
-{ echo "# tools/bin/gemm_bench wxptsu on MI355X (libfishmi.so sha1 $SHA, tree $HEAD): w = wave-specialised 128x128 (round 3), x = 128x256 three-stage tile (round 3), p / u / s / t = linear_tiled_256p_kernel with 256 / 192 / 128 / 64-row tiles (round 4: what launch_linear_tiled chooses among); every variant checked bit for bit against the 4-wave LDS-staged kernel"; tools/bin/gemm_bench wxptsu; } > "$OUT/${TAG}_gemm_bench.txt" 2>&1
+{ echo "# tools/bin/gemm_bench wxptsua on MI355X (libfishmi.so sha1 $SHA, tree $HEAD): w = wave-specialised 128x128 (round 3), x = 128x256 three-stage tile (round 3), p / u / s / t = linear_tiled_256p_kernel with 256 / 192 / 128 / 64-row tiles (round 4: what launch_linear_tiled chooses among); a = what the library selects (round 6: w2 with the contraction split in three + a reduce pass); every other variant checked bit for bit against the 4-wave LDS-staged kernel"; tools/bin/gemm_bench wxptsua; } > "$OUT/${TAG}_gemm_bench.txt" 2>&1
 fi
 # round-5 probes (binaries from tools/build_tools.sh; each prints its own reading): sampler stages, the K-slice GEMV
 # decomposition, Infinity-Cache residency, prefetch from the previous kernel; the overlapped step against the serial one

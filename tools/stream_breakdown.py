@@ -21,7 +21,8 @@ def timed(fn, n=3):
     return min(ts) * 1e3
 full = timed(lambda: codec.from_indices(codes.clone()))
 marks = chunk_schedule(T, 8, 32)
-for cached in (False, True):
+only = os.environ.get("STREAM_ONLY", "")     # "cached": just the stream_id path (for a kernel trace of the chunked decode alone)
+for cached in ((True,) if only == "cached" else (False, True)):
     # cached: the quantizer-side state of frames [0, t0) is kept between the calls of a stream.  Each chunk is timed on
     # the state its predecessor left (a repeated call would not continue it, so the
     # whole stream is replayed for every repetition).
