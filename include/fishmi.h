@@ -202,7 +202,7 @@ int fmi_dualar_set_graph(fmi_dualar* h, int enable);
 int fmi_dualar_set_attn_impl(fmi_dualar* h, int impl);
 /* Fast transformer positions 0 and 1 of a frame (the two forward_generate_fast calls of inference.py:148-149 and :166,
  * whose inputs are both known once the slow token is drawn): 1 = one pass over the fast weights with 2 x batch rows
- * (default when 2 x batch <= 16, bf16 weights, fast_dim == dim), 0 = two passes (rounds 1-3; kept for A/B parity runs).
+ * (default when 2 x batch <= 32, bf16 weights, fast_dim == dim), 0 = two passes (rounds 1-3; kept for A/B parity runs).
  * Results are bit-identical either way, tokens and float taps (tests/test_s2_parity_gpu.py:
  * test_merged_fast_positions_equal_the_two_pass_path_bit_for_bit_at_batch_5_and_8). */
 int fmi_dualar_set_fast_merge(fmi_dualar* h, int enable);
@@ -310,6 +310,9 @@ int fmi_dac_fp16_overflow(fmi_dac* h, int* overflowed);
  *   fmi_dac_set_stream_options: re-creates the handle's stream with a dispatch priority (-1 highest, 0 default,
  *     1 lowest) or, when cu_mask_words > 0, with a CU mask (bit i = compute unit i may run this handle's kernels;
  *     hipExtStreamCreateWithCUMask) -- the codec can be confined to part of the chip while the loop keeps the rest.
+ *     NOTE: the CU-mask form has no non-blocking flag, so unlike every other handle stream it is a BLOCKING stream: it
+ *     synchronises implicitly with the legacy NULL stream (work torch enqueues on its default stream serialises with
+ *     the codec's).  Give torch a side stream when the mask is in use.
  *   fmi_dac_set_background(h, bytes): a floor under the dynamic LDS of the decode-side conv kernels; above 80 KiB only one
  *     of their work-groups fits a CU, so the frame loop's work-groups can be co-resident instead of queueing behind them
  *     (0 = off, the default: two to three conv work-groups per CU). */
