@@ -135,6 +135,14 @@ struct fmi_dac {
     std::vector<float*> qkv;              // per post-transformer layer: roped q|k|v of every frame [B][3C][cap]
     float* tf_out = nullptr;              // transformer output [B][C][cap]
     float* z = nullptr;                   // upsampled latents [B][latent][4 cap]
+    // decoder left context (round 6): per plane-consuming conv of the decoder with k_eff > 1 -- block b's transposed conv
+    // (1 column) and its three dilated k = 7 convs (6, 18, 54) -- the last k_eff - 1 columns of its input operand planes,
+    // and the last 8 fp32 columns in front of the final conv; two copies, flipped per call (halo_swap reads one, writes
+    // the other).  dec_valid: they belong to frames [0, T) of this stream.
+    std::vector<bf16_t*> dh[2];
+    float* dx[2] = {nullptr, nullptr};
+    int dflip = 0;
+    bool dec_valid = false;
     uint64_t used = 0;                    // LRU stamp
   } st;                                   // the state the kernels of the current call work on
   // states of OTHER streams that are still open (a serving loop interleaves the chunks of several utterances, each
@@ -575,6 +583,138 @@ int run_decoder(fmi_dac* h, float* X, float* Y, int B, int len, float* audio_out
                                 skip_cols * hop, h->stream);
 }
 
+// ---- streaming decoder (round 6): every conv sees the previous chunk's tail as real left context ------------------
+// halo columns of the j-th stateful conv input: block b: [up (1), c7 d1 (6), c7 d3 (18), c7 d9 (54)]
+constexpr int FINAL_HALO = 8;   // fp32 columns kept in front of the final k = 7 conv (6 needed; 8 keeps rows 16-byte aligned)
+inline int dec_halo_cols(int j) {
+  const int r = j & 3;
+  return r == 0 ? 1 : r == 1 ? 6 : r == 2 ? 18 : 54;
+}
+bool decoder_streams(const fmi_dac* h) {
+  const fmi_dac_config& c = h->cfg;
+  static const bool off = []() { const char* e = getenv("FMI_DAC_NO_STREAM_HALO"); return e && atoi(e) != 0; }();   // (A/B: context recompute)
+  if (off || h->cur_planes <= 0 || (c.decoder_dim >> 4) % 16 != 0 || h->dec.size() != 4 || !h->dec_in.w.wb) return false;
+  if (h->dec_in.k != 7) return false;
+  for (const DecBlock& db : h->dec) {
+    if (!db.up.transposed || db.up.k != 2 * db.up.stride) return false;
+    for (int r = 0; r < 3; ++r)
+      if (db.ru[r].c7.k != 7 || db.ru[r].c7.dil != (r == 0 ? 1 : r == 1 ? 3 : 9) || db.ru[r].c1.k != 1) return false;
+  }
+  return true;
+}
+
+int alloc_dec_halos(fmi_dac* h, fmi_dac::StreamState& st, int B) {
+  const fmi_dac_config& c = h->cfg;
+  for (int k = 0; k < 2; ++k) {
+    st.dh[k].assign(16, nullptr);
+    for (int j = 0; j < 16; ++j) {
+      const int bi = j >> 2;
+      const int cin = (j & 3) == 0 ? (c.decoder_dim >> bi) : (c.decoder_dim >> (bi + 1));   // up reads the block's input width
+      const size_t bytes = (size_t)B * (cin / 16) * 2 * dec_halo_cols(j) * 32;
+      FMI_CHECK_HIP(hipMalloc((void**)&st.dh[k][j], bytes));
+    }
+    FMI_CHECK_HIP(hipMalloc((void**)&st.dx[k], (size_t)B * (c.decoder_dim >> 4) * FINAL_HALO * 4));
+  }
+  st.dec_valid = false;
+  return FMI_OK;
+}
+
+int zero_dec_halos(fmi_dac* h, fmi_dac::StreamState& st, int B) {
+  const fmi_dac_config& c = h->cfg;
+  for (int k = 0; k < 2; ++k) {
+    for (int j = 0; j < 16; ++j) {
+      const int bi = j >> 2;
+      const int cin = (j & 3) == 0 ? (c.decoder_dim >> bi) : (c.decoder_dim >> (bi + 1));
+      FMI_CHECK_HIP(hipMemsetAsync(st.dh[k][j], 0, (size_t)B * (cin / 16) * 2 * dec_halo_cols(j) * 32, h->stream));
+    }
+    FMI_CHECK_HIP(hipMemsetAsync(st.dx[k], 0, (size_t)B * (c.decoder_dim >> 4) * FINAL_HALO * 4, h->stream));
+  }
+  st.dflip = 0;
+  return FMI_OK;
+}
+
+// Zin: fp32 latents [B][latent][zl + len], its first zl columns = real left context of the first conv (0 at the start of an
+// utterance); X: fp32 residual-stream buffer; audio of the last (len - skip_cols) latent columns is written.  Same kernels,
+// same products per output element as run_decoder_planes: bit-identical to the offline decode.
+int run_decoder_stream(fmi_dac* h, fmi_dac::StreamState& st, const float* Zin, int zl, float* X, int B, int len,
+                       float* audio_out_dev, int skip_cols) {
+  const fmi_dac_config& c = h->cfg;
+  const int NP = h->cur_planes;
+  hipStream_t s = h->stream;
+  const int64_t pbytes = (int64_t)B * decode_peak_elems(c, cdiv(len, 4) + 8) * 2 * NP;
+  for (int i = 0; i < 2; ++i)
+    if (h->pbuf_bytes[i] < pbytes) {
+      FMI_CHECK_HIP(hipStreamSynchronize(s));
+      if (h->pbuf[i]) hipFree(h->pbuf[i]);
+      h->pbuf[i] = nullptr;
+      h->pbuf_bytes[i] = 0;
+      FMI_CHECK_HIP(hipMalloc((void**)&h->pbuf[i], (size_t)pbytes));
+      h->pbuf_bytes[i] = pbytes;
+    }
+  bf16_t *cur = h->pbuf[0], *oth = h->pbuf[1];
+  const std::vector<bf16_t*>&old_h = st.dh[st.dflip], &new_h = st.dh[st.dflip ^ 1];
+  auto conv = [&](const Conv& cv, const float* x, int x_ld, int x_left, const bf16_t* xp, int xh, float* out, int out_ld,
+                  const float* res, bf16_t* outp, int oh, int lin, int* lout_p, const float* next_alpha) -> int {
+    ConvArgs a{};
+    a.w = cv.w; a.x = x; a.out = out; a.res = res; a.B = B; a.lin = lin; a.act = ACT_NONE; a.planes = NP;
+    a.next_alpha = next_alpha;
+    int lout;
+    if (cv.transposed) {
+      lout = lin * cv.stride;
+      a.x_stride = 1; a.tap_step = -1; a.tap_base = 0; a.out_stride = cv.stride;
+    } else {
+      const int k_eff = (cv.k - 1) * cv.dil + 1;
+      lout = cdiv(lin, cv.stride);
+      a.x_stride = cv.stride; a.tap_step = cv.dil; a.tap_base = -(k_eff - cv.stride); a.out_stride = 1;
+    }
+    a.lout = lout;
+    if (xp) { a.xp = xp + (int64_t)xh * 16; a.x_ld = xh + lin; a.x_left = xh; }
+    else { a.x_ld = x_ld; a.x_left = x_left; }
+    if (outp) { a.outp = outp + (int64_t)oh * 16; a.outp_ld = oh + lout; }
+    a.out_ld = out_ld;
+    if (lout_p) *lout_p = lout;
+    return launch_conv(a, s);
+  };
+  auto swap_in = [&](bf16_t* buf, int j, int cin, int n) -> int {   // halo j of the buffer the next conv reads
+    return launch_halo_swap(buf, old_h[j], new_h[j], (int64_t)B * (cin / 16) * NP, dec_halo_cols(j), n, 32, s);
+  };
+  int l2;
+  // first conv: fp32 z with its own left context; its output only feeds block 0's Snake + transposed conv
+  FMI_CHECK(conv(h->dec_in, Zin + zl, zl + len, zl, nullptr, 0, nullptr, 0, nullptr, cur, dec_halo_cols(0), len, &l2, h->dec[0].alpha));
+  int hop = 1;
+  for (int i = 0; i < 4; ++i) hop *= c.decoder_rates[i];
+  const int len_final = len * hop;
+  float* Xl = X;        // logical column 0 of the fp32 residual stream (moved behind the halo in the last block)
+  int xld = 0;
+  for (size_t bi = 0; bi < h->dec.size(); ++bi) {
+    const DecBlock& db = h->dec[bi];
+    const bool last_block = bi + 1 == h->dec.size();
+    const int cin = c.decoder_dim >> bi, cout = c.decoder_dim >> (bi + 1);
+    FMI_CHECK(swap_in(cur, (int)bi * 4 + 0, cin, len));
+    if (last_block) { Xl = X + FINAL_HALO; xld = FINAL_HALO + len * db.up.stride; }
+    FMI_CHECK(conv(db.up, nullptr, 0, 0, cur, 1, Xl, xld, nullptr, oth, 6, len, &l2, db.ru[0].a1));
+    std::swap(cur, oth);
+    len = l2;
+    for (int r = 0; r < 3; ++r) {
+      const ResUnit& ru = db.ru[r];
+      const int j = (int)bi * 4 + 1 + r;
+      FMI_CHECK(swap_in(cur, j, cout, len));
+      FMI_CHECK(conv(ru.c7, nullptr, 0, 0, cur, dec_halo_cols(j), nullptr, 0, nullptr, oth, 0, len, nullptr, ru.a2));
+      std::swap(cur, oth);
+      const bool last_ru = r == 2;
+      const float* na = !last_ru ? db.ru[r + 1].a1 : (last_block ? nullptr : h->dec[bi + 1].alpha);
+      const int oh = !last_ru ? dec_halo_cols(j + 1) : (last_block ? 0 : dec_halo_cols((int)(bi + 1) * 4));
+      FMI_CHECK(conv(ru.c1, nullptr, 0, 0, cur, 0, Xl, xld, Xl, (last_ru && last_block) ? nullptr : oth, oh, len, nullptr, na));
+      std::swap(cur, oth);
+    }
+  }
+  FMI_REQUIRE(len == len_final, "stream decoder: length bookkeeping");
+  FMI_CHECK(launch_halo_swap(X, st.dx[st.dflip], st.dx[st.dflip ^ 1], (int64_t)B * (c.decoder_dim >> 4), FINAL_HALO, len, 4, s));
+  st.dflip ^= 1;
+  return launch_final_conv_tanh(X, h->dec_alpha, h->final_w, h->final_b, audio_out_dev, B, c.decoder_dim >> 4, FINAL_HALO + len,
+                                FINAL_HALO + skip_cols * hop, s);
+}
+
 int64_t decode_peak_elems(const fmi_dac_config& c, int T) {
   int64_t peak = (int64_t)c.latent_dim * 4 * T;
   int64_t L = 4 * (int64_t)T;
@@ -634,6 +774,14 @@ void free_one_state(fmi_dac::StreamState& st) {
   if (st.tf_out) hipFree(st.tf_out);
   if (st.z) hipFree(st.z);
   st.tf_out = st.z = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    for (bf16_t* p : st.dh[k])
+      if (p) hipFree(p);
+    st.dh[k].clear();
+    if (st.dx[k]) hipFree(st.dx[k]);
+    st.dx[k] = nullptr;
+  }
+  st.dec_valid = false;
   st.B = st.T = st.cap = 0;
   st.id = 0;
 }
@@ -1071,12 +1219,29 @@ int fmi_dac_decode_tail_cached(fmi_dac* h, int64_t* indices_dev, int B, int T, i
     }
   }
   h->st.T = 0;   // invalid until this call has succeeded
+  const bool stream_dec = decoder_streams(h);
+  if (stream_dec && h->st.dh[0].empty()) FMI_CHECK(alloc_dec_halos(h, h->st, B));
+  const bool halos_ok = stream_dec && from == t0 && t0 > 0 && h->st.dec_valid;   // the kept tails are those of frames [0, t0)
+  h->st.dec_valid = false;
   FMI_CHECK(run_quantizer_decode_inc(h, indices_dev, B, T, from));
-  const int ctx_frames = std::min(t0, cdiv(decoder_context_cols(c), up));
+  // left context: none with the kept tails (every conv continues where the previous chunk ended); otherwise -- first call
+  // of a stream at t0 > 0, a dropped state -- the receptive field is recomputed from zero tails and its audio discarded
+  const int ctx_frames = halos_ok ? 0 : std::min(t0, cdiv(decoder_context_cols(c), up));
   const int col_lo = up * (t0 - ctx_frames), w = up * T - col_lo;
-  float *X = h->buf[0].p, *Y = h->buf[1].p;
-  FMI_CHECK(copy_cols(h, X, w, h->st.z + col_lo, up * h->st.cap, w, (int64_t)B * L0));
-  FMI_CHECK(run_decoder(h, X, Y, B, w, audio_out_dev, up * ctx_frames));
+  if (stream_dec) {
+    if (!halos_ok) FMI_CHECK(zero_dec_halos(h, h->st, B));
+    const int zl = halos_ok ? std::min(6, col_lo) : 0;   // the first conv reads its context straight from the kept latents
+    FMI_CHECK(ensure_buf(h, 0, (int64_t)B * decode_peak_elems(c, cdiv(w, up) + 8)));
+    FMI_CHECK(ensure_buf(h, 1, (int64_t)B * L0 * (w + 8)));
+    float *X = h->buf[0].p, *Zin = h->buf[1].p;
+    FMI_CHECK(copy_cols(h, Zin, zl + w, h->st.z + col_lo - zl, up * h->st.cap, zl + w, (int64_t)B * L0));
+    FMI_CHECK(run_decoder_stream(h, h->st, Zin, zl, X, B, w, audio_out_dev, up * ctx_frames));
+    h->st.dec_valid = true;
+  } else {
+    float *X = h->buf[0].p, *Y = h->buf[1].p;
+    FMI_CHECK(copy_cols(h, X, w, h->st.z + col_lo, up * h->st.cap, w, (int64_t)B * L0));
+    FMI_CHECK(run_decoder(h, X, Y, B, w, audio_out_dev, up * ctx_frames));
+  }
   h->st.T = T;
   h->st.id = stream_id;
   h->st.planes = h->cur_planes;

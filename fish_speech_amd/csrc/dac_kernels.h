@@ -52,6 +52,13 @@ struct ConvArgs {
   const bf16_t* xp;
   bf16_t* outp;
   const float* next_alpha;
+  // Streaming decode (round 6, bf16-plane kernel only): buffers wider than the logical lengths, and real data LEFT of
+  // input column 0 -- the tail of the previous chunk that a causal conv's first outputs read (k_eff - 1 columns; one for
+  // the k = 2s transposed convs) -- instead of zero padding.  All pointers address logical column 0.  0 = as before.
+  int x_ld;      // columns per row of x / xp (0: lin)
+  int x_left;    // input columns -x_left .. -1 exist and hold data (0: columns < 0 are padding)
+  int out_ld;    // columns per row of out / res (0: lout)
+  int outp_ld;   // columns per row of outp (0: lout)
   // device word raised when an operand of the fp16 split leaves the fp16 range (owned by the codec handle);
   // nullptr = the one named by set_f16_overflow_target() on this host thread
   int* ovf;
@@ -98,6 +105,12 @@ int launch_lut_decode(const int64_t* idx /*[B][1+n][T]*/, const float* tables, c
 int launch_clamp_indices(int64_t* idx, int B, int n_books1, int T, int sem_size, int cb_size, hipStream_t s);
 int launch_build_lut(const float* codebook /*[n][d]*/, const float* w /*[C][d]*/, const float* bias, float* table,
                      int n, int d, int C, hipStream_t s);
+// Streaming decode (round 6): a buffer row is [h halo columns | n new columns] (row stride h + n elements of ELEM bytes;
+// `buf` addresses the row's first halo column).  Writes the previous chunk's tail (old_state, [rows][h]) into the halo and
+// keeps the tail of [halo | new] -- the last h columns -- in new_state for the next chunk.  elem_bytes: 32 (one column of
+// an operand plane: 16 x 16 bit) or 4 (fp32).
+int launch_halo_swap(void* buf, const void* old_state, void* new_state, int64_t rows, int h, int n, int elem_bytes,
+                     hipStream_t s);
 int launch_final_conv_tanh(const float* x /*[B][C][L]*/, const float* alpha, const float* w /*[C][7]*/,
                            const float* bias, float* out /*[B][1][L-col0]*/, int B, int C, int L, int col0,
                            hipStream_t s);

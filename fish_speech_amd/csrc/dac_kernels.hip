@@ -399,7 +399,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
   const int zph = PH ? a.w.phases / MT : a.w.phases;          // phase groups per utterance
   const int b = blockIdx.z / zph, phase = (blockIdx.z % zph) * (PH ? MT : 1);
   const int c0 = q0 * a.x_stride + a.tap_base - tap_off0;
-  const float* xb = a.x + (int64_t)b * a.w.cin * a.lin;
+  const int xld = a.x_ld ? a.x_ld : a.lin;                    // (streaming: row strides / left context, see ConvArgs)
+  const int old_ = a.out_ld ? a.out_ld : a.lout, opld = a.outp_ld ? a.outp_ld : a.lout;
+  const int xlo = -a.x_left;
+  const float* xb = a.x + (int64_t)b * a.w.cin * xld;
   const int cgs = a.w.cin_pad16 >> 4;
   // plane 0 of (phase, tap 0, group 0), rows from co0
   const bf16_t* wph = a.w.wb + ((((int64_t)phase * taps * cgs * 3) * a.w.cout_pad + co0) << 4);
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
   for (int cg0 = 0; cg0 < cgs; cg0 += G) {
     fetch_w(cg0, 0, wt < taps ? wt : taps);
     if (a.xp) {   // operand planes written by the producing conv: a plain copy (two lanes per 32-byte column)
-      const char* xpb = reinterpret_cast<const char*>(a.xp) + (int64_t)b * cgs * NP * a.lin * 32;
+      const char* xpb = reinterpret_cast<const char*>(a.xp) + (int64_t)b * cgs * NP * xld * 32;
       const int nb32 = (wx + 31) >> 5;
       for (int it = wave; it < G * NP * nb32; it += 4) {
         const int gp = it / nb32, cb = it - gp * nb32;
@@ -448,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
         const int col = c0 + c;
         if (c < wx) {
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (col >= 0 && col < a.lin)
-            v = *reinterpret_cast<const u32x4*>(xpb + (((int64_t)(cg0 + g) * NP + pl) * a.lin + col) * 32 + h * 16);
+          if (col >= xlo && col < a.lin)
+            v = *reinterpret_cast<const u32x4*>(xpb + (((int64_t)(cg0 + g) * NP + pl) * xld + col) * 32 + h * 16);
           *reinterpret_cast<u32x4*>(Xs + ((int64_t)(g * NP + pl) * wx + c) * 32 + (((h ^ (c >> 3)) & 1) << 4)) = v;
         }
       }
@@ -469,15 +472,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
         const int nval = a.w.cin - ci;           // real channels among the 8 (padding reads as zero)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
-        if (it < 2 * G * nblk && c < wx && col >= 0 && col < a.lin && nval > 0) {
-          const float* xp = xb + (int64_t)ci * a.lin + col;
+        if (it < 2 * G * nblk && c < wx && col >= xlo && col < a.lin && nval > 0) {
+          const float* xp = xb + (int64_t)ci * xld + col;
           if (nval >= 8) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[u][e] = xp[(int64_t)e * a.lin];
+            for (int e = 0; e < 8; ++e) v[u][e] = xp[(int64_t)e * xld];
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-              if (e < nval) v[u][e] = xp[(int64_t)e * a.lin];
+              if (e < nval) v[u][e] = xp[(int64_t)e * xld];
           }
         }
       }
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
         const int col = c0 + c;
         const int nval = a.w.cin - ci;
         if (it < 2 * G * nblk && c < wx) {
-          if (do_snake && col >= 0 && col < a.lin) {
+          if (do_snake && col >= xlo && col < a.lin) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
               if (e < nval) v[u][e] = snake_f(v[u][e], a.snake_alpha[ci + e]);
@@ -580,8 +583,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
     sg[tid] = a.gamma ? a.gamma[co] : 1.f;
   }
   __syncthreads();
-  float* ob = a.out ? a.out + (int64_t)b * a.w.cout * a.lout : nullptr;
-  const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * a.lout : ob;
+  float* ob = a.out ? a.out + (int64_t)b * a.w.cout * old_ : nullptr;
+  const float* rb = a.res ? a.res + (int64_t)b * a.w.cout * old_ : ob;
   const bool has_res = a.res != nullptr;
   auto finish = [&](float accv, float acxv, float bias, float gam, float resv) {
     float v = (NP == 2 ? accv + acxv * (1.0f / F16_LO_SCALE) : accv) + bias;
@@ -608,9 +611,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
       h1 = cvt_pk_bf16_f32(t[2], t[3]);
     }
     char* dst = reinterpret_cast<char*>(a.outp) +
-                ((((int64_t)b * (a.w.cout >> 4) + (co >> 4)) * NP) * a.lout + col) * 32 + (co & 15) * 2;
+                ((((int64_t)b * (a.w.cout >> 4) + (co >> 4)) * NP) * opld + col) * 32 + (co & 15) * 2;
     *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-    if (NP == 2) *reinterpret_cast<uint2*>(dst + (int64_t)a.lout * 32) = make_uint2(l0, l1);
+    if (NP == 2) *reinterpret_cast<uint2*>(dst + (int64_t)opld * 32) = make_uint2(l0, l1);
   };
   if constexpr (PH) {
     // tile i = phase + i: the lane's MT values of (channel, input column q) are MT consecutive output columns
@@ -632,11 +635,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
           const int coe = min(co + e, co_last);
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            const float rv = has_res ? rb[(int64_t)coe * a.lout + col0 + i] : 0.f;
+            const float rv = has_res ? rb[(int64_t)coe * old_ + col0 + i] : 0.f;
             o[i][e] = finish(acc[i][j][r], NP == 2 ? acx[i][j][r] : 0.f, b4[e], g4[e], rv);
           }
           if (a.out && live && co + e <= co_last) {
-            float* dst = ob + (int64_t)(co + e) * a.lout + col0;
+            float* dst = ob + (int64_t)(co + e) * old_ + col0;
             if constexpr (MT == 4) *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0][e], o[1][e], o[2][e], o[3][e]};
             else if constexpr (MT == 2) *reinterpret_cast<float2*>(dst) = make_float2(o[0][e], o[1][e]);
             else {
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = min(co0 + row0 + 8 * (r >> 2) + (r & 3), co_last);
-          rv[r] = has_res ? rb[co * a.lout + col] : 0.f;
+          rv[r] = has_res ? rb[(int64_t)co * old_ + col] : 0.f;
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvArgs a, int 
             const int r = r4 * 4 + e;
             const float v = finish(acc[i][j][r], NP == 2 ? acx[i][j][r] : 0.f, b4[e], g4[e], rv[r]);
             const int co = co0 + row0 + 8 * r4 + e;
-            if (a.out && live && co <= co_last) ob[co * a.lout + col] = v;
+            if (a.out && live && co <= co_last) ob[(int64_t)co * old_ + col] = v;
             o4[e] = v;
           }
           if (a.outp) {
@@ -790,7 +793,8 @@ static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span
   // phase-tiled transposed convs (FMI_CONV_PH=0: one phase per work-group, A/B): 4 (stride 4, 8) or 2 phases per
   // work-group; the output-column vector store needs lout rows 16-byte aligned per 4 columns
   static const int env_ph = []() { const char* e = getenv("FMI_CONV_PH"); return e ? atoi(e) : 1; }();
-  if (env_ph && w.phases >= 2 && w.taps != 7 && a.out_stride == w.phases && w.cout_pad % 32 == 0 && a.lout % 4 == 0) {
+  if (env_ph && w.phases >= 2 && w.taps != 7 && a.out_stride == w.phases && w.cout_pad % 32 == 0 &&
+      (a.out_ld ? a.out_ld : a.lout) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
     const int cgs = w.cin_pad16 >> 4;
     const int g = (env_ph >= 2 || cgs % 2) ? 1 : 2;
     if (w.phases % 4 == 0) {
@@ -970,6 +974,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t s) {
   const int ncols = (a.out_stride == 1) ? a.lout : a.lout / a.out_stride;
   const int tap_off0 = (a.tap_step < 0) ? -(w.taps - 1) * a.tap_step : 0;
   const int span = (w.taps - 1) * (a.tap_step < 0 ? -a.tap_step : a.tap_step) + 1;
+  FMI_REQUIRE(a.planes > 0 || (!a.x_ld && !a.x_left && !a.out_ld && !a.outp_ld), "conv: streaming strides need the bf16-plane kernel");
   if (a.planes > 0) {
     FMI_REQUIRE(w.wb && w.cin_pad16 % 16 == 0, "conv: this layer has no bf16 planes (planes=%d requested)", a.planes);
     if (a.planes == 1) return launch_conv_bf16<1>(a, ncols, tap_off0, span, s);
@@ -1592,6 +1597,35 @@ int launch_final_conv_tanh(const float* x, const float* alpha, const float* w, c
   const size_t smem = (size_t)(32 * (256 + 6) + 32 * 7) * sizeof(float);
   hipLaunchKernelGGL(final_conv_tanh_kernel, dim3(cdiv(L - col0, 256), B), dim3(256), smem, s, x, alpha, w, bias, out,
                      C, L, col0);
+  FMI_CHECK_HIP(hipGetLastError());
+  return FMI_OK;
+}
+
+// one thread per (row, halo column, 4-byte word of the element)
+__global__ void halo_swap_kernel(uint32_t* __restrict__ buf, const uint32_t* __restrict__ old_state, uint32_t* __restrict__ new_state,
+                                 int64_t total, int h, int n, int ew) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int wd = (int)(idx % ew);
+  const int j = (int)((idx / ew) % h);
+  const int64_t row = idx / ((int64_t)ew * h);
+  const int64_t ld = (int64_t)(h + n) * ew;
+  uint32_t* r = buf + row * ld;
+  const uint32_t* o = old_state + row * (int64_t)h * ew;
+  // S = [old (h) | new (n)]; the next state is S[n .. n + h): taken from old where it still reaches into the halo
+  const uint32_t keep = (n + j < h) ? o[(int64_t)(n + j) * ew + wd] : r[(int64_t)(n + j) * ew + wd];
+  const uint32_t front = o[(int64_t)j * ew + wd];
+  new_state[(row * h + j) * ew + wd] = keep;
+  r[(int64_t)j * ew + wd] = front;    // (position j < h: read above only as S[n + j] with n + j >= h, i.e. never: no hazard)
+}
+
+int launch_halo_swap(void* buf, const void* old_state, void* new_state, int64_t rows, int h, int n, int elem_bytes,
+                     hipStream_t s) {
+  FMI_REQUIRE(h >= 1 && n >= 1 && elem_bytes % 4 == 0 && old_state != new_state, "halo_swap: bad arguments");
+  const int ew = elem_bytes / 4;
+  const int64_t total = rows * h * ew;
+  hipLaunchKernelGGL(halo_swap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (uint32_t*)buf,
+                     (const uint32_t*)old_state, (uint32_t*)new_state, total, h, n, ew);
   FMI_CHECK_HIP(hipGetLastError());
   return FMI_OK;
 }
