@@ -139,8 +139,10 @@ struct fmi_dac {
     // (1 column) and its three dilated k = 7 convs (6, 18, 54) -- the last k_eff - 1 columns of its input operand planes,
     // and the last 8 fp32 columns in front of the final conv; two copies, flipped per call (halo_swap reads one, writes
     // the other).  dec_valid: they belong to frames [0, T) of this stream.
-    std::vector<bf16_t*> dh[2];
+    std::vector<bf16_t*> dh[2];           // (pointers into dslab)
     float* dx[2] = {nullptr, nullptr};
+    char* dslab[2] = {nullptr, nullptr};  // one allocation per copy: cleared by one memset
+    size_t dslab_bytes = 0;
     int dflip = 0;
     bool dec_valid = false;
     uint64_t used = 0;                    // LRU stamp
@@ -605,30 +607,29 @@ bool decoder_streams(const fmi_dac* h) {
 
 int alloc_dec_halos(fmi_dac* h, fmi_dac::StreamState& st, int B) {
   const fmi_dac_config& c = h->cfg;
-  for (int k = 0; k < 2; ++k) {
-    st.dh[k].assign(16, nullptr);
-    for (int j = 0; j < 16; ++j) {
-      const int bi = j >> 2;
-      const int cin = (j & 3) == 0 ? (c.decoder_dim >> bi) : (c.decoder_dim >> (bi + 1));   // up reads the block's input width
-      const size_t bytes = (size_t)B * (cin / 16) * 2 * dec_halo_cols(j) * 32;
-      FMI_CHECK_HIP(hipMalloc((void**)&st.dh[k][j], bytes));
-    }
-    FMI_CHECK_HIP(hipMalloc((void**)&st.dx[k], (size_t)B * (c.decoder_dim >> 4) * FINAL_HALO * 4));
+  size_t off[17], total = 0;
+  for (int j = 0; j < 16; ++j) {
+    const int bi = j >> 2;
+    const int cin = (j & 3) == 0 ? (c.decoder_dim >> bi) : (c.decoder_dim >> (bi + 1));   // up reads the block's input width
+    off[j] = total;
+    total += (size_t)B * (cin / 16) * 2 * dec_halo_cols(j) * 32;       // two planes at most
   }
+  off[16] = total;
+  total += (size_t)B * (c.decoder_dim >> 4) * FINAL_HALO * 4;
+  for (int k = 0; k < 2; ++k) {
+    FMI_CHECK_HIP(hipMalloc((void**)&st.dslab[k], total));
+    st.dh[k].assign(16, nullptr);
+    for (int j = 0; j < 16; ++j) st.dh[k][j] = reinterpret_cast<bf16_t*>(st.dslab[k] + off[j]);
+    st.dx[k] = reinterpret_cast<float*>(st.dslab[k] + off[16]);
+  }
+  st.dslab_bytes = total;
   st.dec_valid = false;
   return FMI_OK;
 }
 
 int zero_dec_halos(fmi_dac* h, fmi_dac::StreamState& st, int B) {
-  const fmi_dac_config& c = h->cfg;
-  for (int k = 0; k < 2; ++k) {
-    for (int j = 0; j < 16; ++j) {
-      const int bi = j >> 2;
-      const int cin = (j & 3) == 0 ? (c.decoder_dim >> bi) : (c.decoder_dim >> (bi + 1));
-      FMI_CHECK_HIP(hipMemsetAsync(st.dh[k][j], 0, (size_t)B * (cin / 16) * 2 * dec_halo_cols(j) * 32, h->stream));
-    }
-    FMI_CHECK_HIP(hipMemsetAsync(st.dx[k], 0, (size_t)B * (c.decoder_dim >> 4) * FINAL_HALO * 4, h->stream));
-  }
+  (void)B;
+  for (int k = 0; k < 2; ++k) FMI_CHECK_HIP(hipMemsetAsync(st.dslab[k], 0, st.dslab_bytes, h->stream));
   st.dflip = 0;
   return FMI_OK;
 }
@@ -775,12 +776,12 @@ void free_one_state(fmi_dac::StreamState& st) {
   if (st.z) hipFree(st.z);
   st.tf_out = st.z = nullptr;
   for (int k = 0; k < 2; ++k) {
-    for (bf16_t* p : st.dh[k])
-      if (p) hipFree(p);
     st.dh[k].clear();
-    if (st.dx[k]) hipFree(st.dx[k]);
     st.dx[k] = nullptr;
+    if (st.dslab[k]) hipFree(st.dslab[k]);
+    st.dslab[k] = nullptr;
   }
+  st.dslab_bytes = 0;
   st.dec_valid = false;
   st.B = st.T = st.cap = 0;
   st.id = 0;

@@ -813,6 +813,18 @@ static int launch_conv_bf16(const ConvArgs& a, int ncols, int tap_off0, int span
     for (int g : {4, 2})
       if (g <= env_upg && cgs % g == 0 && (size_t)g * NP * (wxu + w.taps * MT * 32) * 32 <= 80 * 1024) { ug = g; break; }
   }
+  // k = 7 convs on a SMALL grid (the first chunks of a streaming decode: a few hundred columns per utterance): every
+  // work-group walks C_in / 16 copy -> barrier -> products -> barrier steps with nobody else on its CU to hide them
+  // (block 0 of the decoder: 48 steps, ~130 us whatever the width).  Two channel groups per step, the whole k = 7 tile
+  // resident (109 KiB of LDS: one work-group per CU, which a small grid has anyway), halve the chain; group-major
+  // products, so the bits do not change.  FMI_CONV_K7_SMALL = work-group count below which this form is used (0: never).
+  static const int env_k7 = []() { const char* e = getenv("FMI_CONV_K7_SMALL"); return e ? atoi(e) : 300; }();
+  if (!k1 && w.taps == 7 && NP == 2 && MT == 3 && a.x_stride == 1 && env_k7 > 0) {
+    const int cgs = w.cin_pad16 >> 4;
+    const int64_t wgs = (int64_t)cdiv(ncols, 128) * (w.cout_pad / 96) * a.B * w.phases;
+    const int wxu = 127 * a.x_stride + span;
+    if (wgs < env_k7 && cgs % 2 == 0 && (size_t)2 * NP * (wxu + w.taps * MT * 32) * 32 <= 150 * 1024) ug = 2;
+  }
 #define FMI_CONVB(MT_, NT_)                                                              \
   do {                                                                                   \
     if (!k1 && ug == 4 && MT_ == 3 && NT_ == 1) return launch_conv_bf16_t<3, 1, 4, NP>(a, ncols, tap_off0, span, s); \
