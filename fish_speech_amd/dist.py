@@ -32,6 +32,22 @@ def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_bytes: int = 1 << 30
 
     flat = buf.view(-1)
     n = flat.numel()
+    if flat.is_cuda and "nccl" not in str(dist.get_backend(group)):
+        # A non-RCCL backend (gloo: the CPU tests and the one-GPU multi-rank debug mode) is handed HOST tensors, staged
+        # here with synchronous copies.  gloo does accept device tensors -- it stages them through pinned buffers and
+        # copies on streams of its own -- and that path, between ranks that share one GPU, is what the GPU memory access
+        # faults of profiles/r06_startup_order_stress.txt need: ranks that skip the broadcast never fault.
+        host = torch.empty(min(n, chunk_bytes), dtype=torch.uint8)
+        rank = dist.get_rank(group)
+        for off in range(0, n, chunk_bytes):
+            piece = flat[off: min(n, off + chunk_bytes)]
+            h = host[: piece.numel()]
+            if rank == src:
+                h.copy_(piece)                      # D2H, returns when done
+            dist.broadcast(h, src=src, group=group)
+            if rank != src:
+                piece.copy_(h)                      # H2D from pageable memory: returns when the bytes have left the host
+        return
     for off in range(0, n, chunk_bytes):
         dist.broadcast(flat[off: min(n, off + chunk_bytes)], src=src, group=group)
 
