@@ -188,6 +188,7 @@ def test_bench_rank1_construction_order_through_broadcast_arena(monkeypatch):
 
     monkeypatch.setattr(dist, "broadcast", fake_broadcast)
     monkeypatch.setattr(dist, "get_rank", lambda group=None: 1)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")   # the device-tensor path, as over RCCL
     order = iter([m0, c0])
 
     def replicate(obj):
