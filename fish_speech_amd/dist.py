@@ -58,12 +58,10 @@ def broadcast_arena(model, src: int = 0, group=None, chunk_bytes: int = 1 << 30)
     Ordering is the product's, not the caller's.  (1) A blocking `dist.broadcast` returns with torch's current stream
     ordered after the collective (RCCL / gloo run it on their own streams), and `weights_ready()` makes the model's
     private stream -- on which the first prefill derives the row-balanced copies and the q|k|v table FROM the arena --
-    wait for the current stream.  (2) The call ends with a DEVICE synchronize on every rank: stream order alone was
-    measured not to be enough -- with the collective's last copies still in flight when the host goes on to submit the
-    first step (120 hipMallocs, pageable H2D copies, the first launches), ranks > 0 died with a GPU memory access fault
-    in 4 of 5 world-4 launches, ordered or not, and in 0 of 18 iterations once start-up ends with a synchronize
-    (tools/startup_order_stress.py, profiles/r06_startup_order_stress.txt).  Start-up is untimed; the wait is the
-    broadcast's own duration.  Callers need no synchronize of their own."""
+    wait for the current stream.  (2) The call ends with a device synchronize on every rank -- defensive: start-up is
+    untimed, and it leaves every rank quiet before anybody's first step.  (The GPU memory faults of the one-GPU
+    multi-rank debug mode that this was first added against turned out to belong to gloo's device-tensor broadcast, see
+    broadcast_buffer and profiles/r06_startup_order_stress.txt.)  Callers need no synchronize of their own."""
     import torch.distributed as dist
 
     broadcast_buffer(model.arena, src=src, chunk_bytes=chunk_bytes, group=group)
