@@ -438,7 +438,9 @@ def run_config4(model, codec, cfg, rank, world, dist, device, per_gpu=BATCH):
     t0 = time.perf_counter()
     n_frames = once()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt, dt, float(n_frames)], device=device, dtype=torch.float64)
+    # (reductions travel as device tensors over RCCL; in the one-GPU gloo debug mode as HOST tensors: gloo's device-tensor
+    # path between ranks that share a GPU is what profiles/r06_startup_order_stress.txt found faulting)
+    t = torch.tensor([dt, dt, float(n_frames)], device="cpu" if ONE_GPU_DEBUG else device, dtype=torch.float64)
     if dist:
         mx = t.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -606,7 +608,7 @@ def run_config5_staggered(model, codec, cfg, n_req=16, gap_s=0.25):
 
 
 # FMI_BENCH_ONE_GPU=1: a DEBUG mode for boxes with one GPU -- every rank of `--gpus N` uses cuda:0 and the process group is
-# gloo (RCCL refuses two ranks on one device; gloo carries device tensors).  It executes bench.py's own N > 1 path end to
+# gloo (RCCL refuses two ranks on one device; gloo is handed host tensors, dist.broadcast_buffer).  It executes bench.py's own N > 1 path end to
 # end -- the re-exec under torch.distributed.run, per-rank construction, both arena broadcasts, the barriers, the MAX / SUM
 # reductions, rank 0's JSON line -- with the ranks time-slicing one GPU, so its numbers are NOT a result (the line says so).
 ONE_GPU_DEBUG = os.environ.get("FMI_BENCH_ONE_GPU", "0") not in ("", "0")
@@ -738,7 +740,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if ONE_GPU_DEBUG else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

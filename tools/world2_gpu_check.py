@@ -8,8 +8,7 @@ load_tensor / finalize), the eight reference-written S2 utterances (tests/golden
 sharded r::2 (dist.shard_utterances = tools/vqgan/extract_vq.py:207's files[RANK::WORLD_SIZE]), generated per rank with
 NO data-path collective, gathered (dist.gather_results) and compared with the fixtures on rank 0; each rank decodes its
 utterances' codes with its codec, rank 0 re-decodes rank 1's and requires bit equality; bench.py's MAX / SUM reductions
-run across the two.  Prints WORLD2_GPU_OK (rank 0) on success, GLOO_CUDA_UNSUPPORTED if this torch build's gloo cannot
-carry device tensors.  Started without RANK in the environment it spawns the two ranks itself."""
+run across the two.  Prints WORLD2_GPU_OK (rank 0) on success.  Started without RANK in the environment it spawns the two ranks itself."""
 import json
 import os
 import socket
@@ -52,14 +51,10 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    probe = torch.full((4,), float(rank + 1), device=dev)
-    try:
-        dist.broadcast(probe, src=0)
-        torch.cuda.synchronize()
-    except Exception as e:  # noqa: BLE001
-        if rank == 0:
-            print("GLOO_CUDA_UNSUPPORTED", repr(e)[:300], flush=True)
-        return
+    # (gloo sees HOST tensors only: its device-tensor path between ranks that share one GPU is what the GPU memory access
+    # faults of profiles/r06_startup_order_stress.txt need; dist.broadcast_buffer stages through host itself)
+    probe = torch.full((4,), float(rank + 1))
+    dist.broadcast(probe, src=0)
     assert probe.tolist() == [1.0] * 4
 
     from fish_speech_amd.dac import DacConfig, MiDAC
@@ -124,7 +119,7 @@ def main():
     all_tok = gather_results(out, world, rank)
     all_wav = gather_results(wavs, world, rank)
     # bench.py's reductions (max over ranks of the elapsed time, sum of the audio seconds)
-    t = torch.tensor([float(rank + 1), 2.0], device=dev, dtype=torch.float64)
+    t = torch.tensor([float(rank + 1), 2.0], dtype=torch.float64)
     mx = t.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
