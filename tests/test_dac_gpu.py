@@ -382,6 +382,20 @@ def test_fp16_split_saturates_and_flags_instead_of_producing_nans(small):
     got = safe.from_indices(codes.clone().to(DEV))
     want = D.DacOracle(cfg, big).from_indices(codes.clone())
     assert safe.overflow_fallbacks == 1 and rms(got, want) <= 1e-4 * max(1.0, float(want.abs().max()))
+    # in ASYNC mode a call cannot be redone on the fp32 matrix cores behind the caller's back (its output
+    # was handed out before the codec's stream ran), so the overflow is REPORTED where the caller waits -- synchronize()
+    # raises -- instead of being silently skipped; leaving async mode drains the flag, and the next synchronous call on
+    # other input neither sees a stale flag nor pins anything
+    from fish_speech_amd import FishmiError
+
+    safe.set_async(True)
+    out_async = safe.from_indices(codes.clone().to(DEV))
+    with pytest.raises(FishmiError):
+        safe.synchronize()
+    assert bool(torch.isfinite(out_async).all())
+    safe.synchronize()                                   # the flag was consumed by the report
+    safe.set_async(False)
+    assert not safe.fp16_overflowed()
 
 
 def test_fp16_overflow_flag_belongs_to_the_handle_that_overflowed(small):

@@ -99,6 +99,16 @@ def test_cached_tail_decode_is_bit_identical_and_survives_interleaving(small_cod
         codec.stream_reset()
         got = codec.from_indices_tail(a[:, :, :12].clone(), 3, stream_id=ia)
         assert torch.equal(got, wa[..., 3 * fl:12 * fl])
+        # round 6: the decoder's kept left context.  A call that had to START OVER at t0 > 0 (no state: the receptive
+        # field is recomputed from zero tails, its audio discarded) leaves exact tails behind, so the calls that CONTINUE
+        # it -- one frame, then more than the longest tail (54 columns = 2 frames at the first block) -- are offline's bits
+        ic = codec.new_stream_id()
+        got = codec.from_indices_tail(b[:, :, :20].clone(), 14, stream_id=ic)
+        assert torch.equal(got, wb[..., 14 * fl:20 * fl])
+        got = codec.from_indices_tail(b[:, :, :21].clone(), 20, stream_id=ic)
+        assert torch.equal(got, wb[..., 20 * fl:21 * fl])
+        got = codec.from_indices_tail(b[:, :, :40].clone(), 21, stream_id=ic)
+        assert torch.equal(got, wb[..., 21 * fl:40 * fl])
     codec.stream_reset()
 
 
