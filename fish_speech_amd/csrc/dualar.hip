@@ -1519,7 +1519,7 @@ int fmi_op_linear_bf16(const void* x_dev, const void* w_dev, const void* norm_w_
         a.norm_w = nullptr;
       }
       float* part = nullptr;   // (the shape may run with a split contraction: linear_tiled_ksplit)
-      if (rc == FMI_OK && force_path == 2 && linear_tiled_part_floats(M, N, K) > 0) {
+      if (rc == FMI_OK && (force_path == 2 || force_path == 0) && linear_tiled_part_floats(M, N, K) > 0) {
         if (hipMalloc((void**)&part, (size_t)linear_tiled_part_floats(M, N, K) * 4) != hipSuccess) rc = set_error(FMI_EHIP, "hipMalloc");
         a.part = part;
       }
