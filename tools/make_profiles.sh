@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r03}
 shift || true
-SECTIONS=${*:-step codec prefill pmc attn stream gemm}      # optional: only these sections (+ "probes", round 5)
+SECTIONS=${*:-step codec prefill pmc attn stream gemm}      # optional: only these sections (+ "probes", round 5; "pmcsq", round 6)
 want() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
@@ -64,6 +64,27 @@ for name, n, avg, mn in rows:
     print(f"  {avg:8.2f} us avg ({mn:.2f} min) x{n:5d}  {name[:90]}{extra}")
 PY
 done
+fi
+
+# SQ counters (round 6): what the waves of the dominant kernels do with their cycles -- the decode GEMVs park on memory
+# (WAIT_ANY), the prefill GEMM / codec convs show how busy the matrix pipe is.  Own passes (never with --stats / traces
+# beyond --kernel-trace); 8 SQ slots per pass.
+if want pmcsq; then
+sq_pass() {   # name, counters, header, command...
+  local name=$1 ctr=$2 hdr=$3; shift 3
+  ( cd /tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$W/sq_$name" -o p -- "$@" ) > "$OUT/sq_${name}_run.log" 2>&1
+  local csv; csv=$(find "$W/sq_$name" -name '*counter_collection.csv' | head -1)
+  { echo "# $hdr"; echo "# rocprofv3 --pmc $ctr (libfishmi.so sha1 $SHA, tree $HEAD); per kernel and grid: counter sums over its dispatches, and the share of SQ_WAVE_CYCLES";
+    echo "# WAIT_ANY = wave parked (s_waitcnt / barrier), WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY = issuing; MFMA_BUSY / BUSY_CYCLES ~ matrix-pipe utilisation of the busy CUs";
+    python "$R/tools/pmc_summary.py" "$csv" | head -120; } > "$OUT/${TAG}_pmc_sq_${name}.txt" 2>&1
+}
+sq_pass decode "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" \
+  "decode frame kernels: bench.py --frames 12 --steps 1 --warmup 0 --no-codec --no-extras --no-cpu-baseline" \
+  python "$R/bench.py" --frames 12 --steps 1 --warmup 0 --no-codec --no-extras --no-cpu-baseline
+sq_pass codec "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT" \
+  "codec decode (B = 8, T = 215, fp16 split): tools/codec_bench.py" env PLANES=2 python "$R/tools/codec_bench.py"
+sq_pass prefill "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT" \
+  "prefill of 8 x 200 tokens: tools/prefill_bench.py 200" python "$R/tools/prefill_bench.py" 200
 fi
 
 # timing-only runs (no profiler): streaming breakdown + latency
