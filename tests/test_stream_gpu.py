@@ -112,6 +112,36 @@ def test_cached_tail_decode_is_bit_identical_and_survives_interleaving(small_cod
     codec.stream_reset()
 
 
+@pytest.mark.parametrize("mode", ["fp16_split", "autocast_bf16"])
+def test_streamed_chunks_equal_offline_for_random_schedules(full_codec, mode):
+    """Round 6 (decoder tails kept per stream): random chunk schedules -- one-frame chunks, chunks shorter and longer than
+    the longest kept tail (54 columns = 2 frames at the first decoder block), batch 1 and 3 -- concatenate to the offline
+    decode bit for bit, in the default fp16-split arithmetic and in the engine's autocast(bf16) mode (one operand plane:
+    the tails then hold one plane per column)."""
+    import contextlib
+    import random
+
+    cfg, _, codec = full_codec
+    ctx = (lambda: torch.autocast(device_type="cuda", dtype=torch.bfloat16)) if mode == "autocast_bf16" else contextlib.nullcontext
+    rng = random.Random(606)
+    for trial in range(4):
+        B = 1 if trial % 2 == 0 else 3
+        T = rng.randint(20, 70)
+        cuts = sorted(set(rng.sample(range(1, T), rng.randint(2, 7))))
+        codes = D.make_codes(cfg, B, T, seed=100 + trial).to(DEV)
+        with ctx():
+            want = codec.from_indices(codes.clone())
+            sid = codec.new_stream_id()
+            pieces, t0 = [], 0
+            for t1 in cuts + [T]:
+                pieces.append(codec.from_indices_tail(codes[:, :, :t1].clone(), t0, stream_id=sid))
+                t0 = t1
+            codec.close_stream(sid)
+        got = torch.cat(pieces, dim=-1)
+        assert got.dtype == want.dtype and torch.equal(got, want), (mode, trial, B, T, cuts, float((got.float() - want.float()).abs().max()))
+    codec.stream_reset()
+
+
 def test_cached_tail_decode_long_stream_full_size(full_codec):
     """beyond the attention window (tf_window frames) and across a capacity doubling (1024 frames)"""
     cfg, _, codec = full_codec
