@@ -974,10 +974,13 @@ __global__ __launch_bounds__(1024, 4) void linear_tiled_256w16_kernel(LinearArgs
 
 int linear_tiled_ksplit(int N, int K) {
   static const bool off = []() { const char* e = getenv("FMI_GEMM_NOSPLIT"); return e && atoi(e) != 0; }();   // (A/B runs)
-  // w2 of the S2-Pro shape (2560 x 9728).  At 8 x 200 rows: 250 work-groups of 64 rows x 256 columns, each bound by the
-  // ~50 GB/s a CU takes operands in at -> 128 us; 210 work-groups of 256 x 256 over a third of K each move 0.52 of the
-  // bytes per CU.  wo (K = 4096) does not pay: what the split saves the partial tiles cost again.
-  if (off || N % 16 != 0 || N < 1024 || N > 2560 || K < 8192 || ((K >> 5) & 1)) return 1;
+  // wo / w2 of the S2-Pro shape (2560 x 4096 / 9728).  At 8 x 200 rows: 250 work-groups of 64 rows x 256 columns, each
+  // bound by the ~50 GB/s a CU takes operands in at; 210 work-groups of 256 x 256 over a third of K each move 0.52 of the
+  // bytes per CU.  w2: 126 -> 102 us in tools/gemm_bench, prefill 21.5 -> 19.9 ms.  wo: the micro-benchmark says no
+  // (54 us either way -- its three weight copies stay in the 256 MB Infinity Cache), the STEP says yes (cold weights:
+  // 74 us unsplit; prefill 19.9 -> 19.3 ms with the split, A/B on one box via FMI_GEMM_SPLIT_KMIN).
+  static const int kmin = []() { const char* e = getenv("FMI_GEMM_SPLIT_KMIN"); return e ? atoi(e) : 4096; }();   // (A/B: 8192 = w2 only)
+  if (off || N % 16 != 0 || N < 1024 || N > 2560 || K < kmin || ((K >> 5) & 1)) return 1;
   return 3;
 }
 

@@ -95,8 +95,8 @@ int launch_repack_rows(const bf16_t* packed16, bf16_t* dst, int N, int K, int ep
 // 4-wave kernel, 2 = LDS-staged wave-specialised kernel; force_direct: operands straight from L2.  All bit-identical.
 int launch_linear_tiled(const LinearArgs& a, hipStream_t s, bool force_direct = false, int variant = 0);
 // Fixed split of the contraction (round 6) for the prefill GEMMs whose 256-column tiling leaves most CUs idle at a few
-// hundred to a few thousand rows (N <= 2560: ten column tiles) and whose K is long enough to pay for a reduce pass (w2:
-// K = 9728): S work-groups per output tile, each over 1 / S of the k-steps, fp32 partial tiles in LinearArgs::part, summed
+// hundred to a few thousand rows (N <= 2560: ten column tiles) and whose K is long enough to pay for a reduce pass (wo, w2:
+// K >= 4096): S work-groups per output tile, each over 1 / S of the k-steps, fp32 partial tiles in LinearArgs::part, summed
 // in range order by a second launch that also runs the epilogue.  S depends on (N, K) ONLY -- never on M -- so a row's
 // bits do not depend on the rows it travels with (prefix reuse, ragged prefill).  1 = no split.
 int linear_tiled_ksplit(int N, int K);
