@@ -389,6 +389,45 @@ __device__ inline void wave_find_bin(SmallShared& sh, int lane, uint32_t k, int 
   }
 }
 
+// ---- lane exchanges inside the VALU (round 6).  sample_small_kernel's tail is ONE wave walking a chain of dependent lane
+// exchanges -- a 64-lane bitonic sort (21 stages), two prefix scans, the arg-max of the race -- and __shfl_* is a
+// ds_bpermute round trip through the LDS crossbar per step.  Exchanges inside a row of 16 lanes are DPP moves:
+// xor 1 / 2 = quad_perm, xor 8 = row_ror:8, xor 4 = row_shl:4 / row_shr:4 selected by lane bit 2.  Pure data movement: the
+// results are the same lanes' values as before, bit for bit.
+template <int MASK>
+__device__ inline int xor_lane(int v, int lane) {
+  if constexpr (MASK == 1) return dpp_i<0xB1>(v);            // quad_perm(1,0,3,2)
+  else if constexpr (MASK == 2) return dpp_i<0x4E>(v);       // quad_perm(2,3,0,1)
+  else if constexpr (MASK == 4) {
+    const int up = dpp_i<0x104>(v), dn = dpp_i<0x114>(v);    // row_shl:4 (lane i <- i + 4), row_shr:4 (lane i <- i - 4)
+    return (lane & 4) ? dn : up;
+  } else if constexpr (MASK == 8) return dpp_i<0x128>(v);    // row_ror:8 (lane i <- (i + 8) % 16 of its row)
+  else return __shfl_xor(v, MASK, 64);
+}
+__device__ inline int xor_lane_rt(int v, int stride, int lane) {   // stride known at compile time after unrolling
+  switch (stride) {
+    case 1: return xor_lane<1>(v, lane);
+    case 2: return xor_lane<2>(v, lane);
+    case 4: return xor_lane<4>(v, lane);
+    case 8: return xor_lane<8>(v, lane);
+    case 16: return xor_lane<16>(v, lane);
+    default: return xor_lane<32>(v, lane);
+  }
+}
+// inclusive prefix sum over the 64 lanes (WIDTH = 64) or over each half-wave (WIDTH = 32): Hillis-Steele inside the rows of
+// 16 (row_shr:1, 2, 4, 8 with zeros shifted in), then the row totals carried across rows (row_bcast15 into rows 1 and 3,
+// row_bcast31 into rows 2 and 3)
+template <int WIDTH>
+__device__ inline int incl_scan_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);            // row_bcast15 -> rows 1, 3
+  if constexpr (WIDTH == 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2, 3
+  return v;
+}
+
 __device__ inline int small_draw(float v, float cum, int vid, int lane, int k, float temperature, float top_p,
                                  uint32_t seed, uint32_t stream, uint32_t frame, uint32_t draw) {
   const float tc = rbf(fmaxf(temperature, rbf(1e-5f)));
@@ -409,8 +448,8 @@ __device__ inline int small_draw(float v, float cum, int vid, int lane, int k, f
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(best_id, o, 64);
+    const float ov = __int_as_float(xor_lane_rt(__float_as_int(best), o, lane));
+    const int oi = xor_lane_rt(best_id, o, lane);
     if (ov > best || (ov == best && oi < best_id)) {
       best = ov;
       best_id = oi;
@@ -531,15 +570,9 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     int pg = b0 + b1 + b2 + b3;
     int pm = wave == 0 ? b0 : (wave == 1 ? b1 : (wave == 2 ? b2 : b3));
     int pb = wave == 0 ? 0 : (wave == 1 ? b0 : (wave == 2 ? b0 + b1 : b0 + b1 + b2));
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const int vg = __shfl_up(pg, off, 32), vm = __shfl_up(pm, off, 32), vb = __shfl_up(pb, off, 32);
-      if (bj >= off) {
-        pg += vg;
-        pm += vm;
-        pb += vb;
-      }
-    }
+    pg = incl_scan_dpp<32>(pg);   // (each half-wave scans the 32 buckets on its own: lanes j and j + 32 agree)
+    pm = incl_scan_dpp<32>(pm);
+    pb = incl_scan_dpp<32>(pb);
     const uint32_t reach = (uint32_t)(__ballot(pg >= k) & 0xffffffffull);   // lanes 0-31: buckets whose prefix holds k keys
     if (reach) {
       jstar = __ffs((int)reach) - 1;
@@ -593,15 +626,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     my_eq += (kr[j] == thr) && (thr != 0) && take_eq;
   }
   if (a.dbg_stop == 4) return;
-  int inc_gt = my_gt, inc_eq = my_eq;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int g = __shfl_up(inc_gt, off, 64), e = __shfl_up(inc_eq, off, 64);
-    if (lane >= off) {
-      inc_gt += g;
-      inc_eq += e;
-    }
-  }
+  const int inc_gt = incl_scan_dpp<64>(my_gt), inc_eq = incl_scan_dpp<64>(my_eq);
   const int c_gt = __builtin_amdgcn_readlane(inc_gt, 63);     // this wave's keys above its threshold (< k; short paths: <= 64)
   const int need_eq = k - c_gt;
   int off_gt = inc_gt - my_gt + (one ? c_base : 0), off_eq = inc_eq - my_eq;
@@ -629,7 +654,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     for (int size = 2; size <= 64; size <<= 1)
 #pragma unroll
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)w, stride, 64);
+        const uint32_t o = (uint32_t)xor_lane_rt((int)w, stride, lane);
         const bool take_max = ((lane & stride) == 0) == ((lane & size) == 0);
         w = take_max ? max(w, o) : min(w, o);
       }
@@ -653,7 +678,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampleArgs a) {
     uint32_t m = max(x, y_rev);
 #pragma unroll
     for (int stride = 32; stride > 0; stride >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)m, stride, 64);
+      const uint32_t o = (uint32_t)xor_lane_rt((int)m, stride, lane);
       m = ((lane & stride) == 0) ? max(m, o) : min(m, o);
     }
     return m;
