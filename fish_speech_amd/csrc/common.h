@@ -53,14 +53,43 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte load
 typedef __attribute__((ext_vector_type(4))) float f32x4;   // 16x16 accumulator
 typedef __attribute__((ext_vector_type(16))) float f32x16; // 32x32 accumulator
 
+// ---- lane exchanges inside the VALU (round 6): lane i <- lane i ^ MASK.  Inside a row of 16 lanes these are DPP moves
+// (xor 1 / 2 = quad_perm, xor 8 = row_ror:8, xor 4 = row_shl:4 / row_shr:4 selected by lane bit 2); across rows they stay
+// ds_bpermute round trips.  Pure data movement: the same partner lanes as __shfl_xor, hence the same bits in any
+// reduction built on them.
+template <int MASK>
+__device__ inline int xor_lane(int v, int lane) {
+  if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm(1,0,3,2)
+  else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm(2,3,0,1)
+  else if constexpr (MASK == 4) {
+    const int up = __builtin_amdgcn_mov_dpp(v, 0x104, 0xF, 0xF, true);   // row_shl:4 (lane i <- i + 4)
+    const int dn = __builtin_amdgcn_mov_dpp(v, 0x114, 0xF, 0xF, true);   // row_shr:4 (lane i <- i - 4)
+    return (lane & 4) ? dn : up;
+  } else if constexpr (MASK == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);   // row_ror:8
+  else return __shfl_xor(v, MASK, 64);
+}
+template <int MASK>
+__device__ inline float xor_lane_f(float v, int lane) { return __int_as_float(xor_lane<MASK>(__float_as_int(v), lane)); }
+
+// xor trees over the 64 lanes in the order 32, 16, 8, 4, 2, 1 (the order every fixture and parity bound was made with)
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = (int)(threadIdx.x & 63);
+  v += xor_lane_f<32>(v, lane);
+  v += xor_lane_f<16>(v, lane);
+  v += xor_lane_f<8>(v, lane);
+  v += xor_lane_f<4>(v, lane);
+  v += xor_lane_f<2>(v, lane);
+  v += xor_lane_f<1>(v, lane);
   return v;
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const int lane = (int)(threadIdx.x & 63);
+  v = fmaxf(v, xor_lane_f<32>(v, lane));
+  v = fmaxf(v, xor_lane_f<16>(v, lane));
+  v = fmaxf(v, xor_lane_f<8>(v, lane));
+  v = fmaxf(v, xor_lane_f<4>(v, lane));
+  v = fmaxf(v, xor_lane_f<2>(v, lane));
+  v = fmaxf(v, xor_lane_f<1>(v, lane));
   return v;
 }
 

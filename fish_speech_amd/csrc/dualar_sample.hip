@@ -392,18 +392,7 @@ __device__ inline void wave_find_bin(SmallShared& sh, int lane, uint32_t k, int 
 // ---- lane exchanges inside the VALU (round 6).  sample_small_kernel's tail is ONE wave walking a chain of dependent lane
 // exchanges -- a 64-lane bitonic sort (21 stages), two prefix scans, the arg-max of the race -- and __shfl_* is a
 // ds_bpermute round trip through the LDS crossbar per step.  Exchanges inside a row of 16 lanes are DPP moves:
-// xor 1 / 2 = quad_perm, xor 8 = row_ror:8, xor 4 = row_shl:4 / row_shr:4 selected by lane bit 2.  Pure data movement: the
-// results are the same lanes' values as before, bit for bit.
-template <int MASK>
-__device__ inline int xor_lane(int v, int lane) {
-  if constexpr (MASK == 1) return dpp_i<0xB1>(v);            // quad_perm(1,0,3,2)
-  else if constexpr (MASK == 2) return dpp_i<0x4E>(v);       // quad_perm(2,3,0,1)
-  else if constexpr (MASK == 4) {
-    const int up = dpp_i<0x104>(v), dn = dpp_i<0x114>(v);    // row_shl:4 (lane i <- i + 4), row_shr:4 (lane i <- i - 4)
-    return (lane & 4) ? dn : up;
-  } else if constexpr (MASK == 8) return dpp_i<0x128>(v);    // row_ror:8 (lane i <- (i + 8) % 16 of its row)
-  else return __shfl_xor(v, MASK, 64);
-}
+// xor_lane<MASK> (common.h).  Pure data movement: the results are the same lanes' values as before, bit for bit.
 __device__ inline int xor_lane_rt(int v, int stride, int lane) {   // stride known at compile time after unrolling
   switch (stride) {
     case 1: return xor_lane<1>(v, lane);
